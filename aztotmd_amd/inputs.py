@@ -1,0 +1,151 @@
+"""Synthetic input generator for the benchmark / parity configurations of SURVEY.md section 8(d).
+
+Produces the reference's own input surface: `atoms.xyz`, `field.txt`, `control.txt`, `cuda.txt`
+(grammar: sys_init.cpp:174-989, cuInit.cu:684-754 of the reference) and, for array-based entry
+points, a plain dict ("case") with the same information.
+
+Species / potentials / electrostatics are given in the reference's *input* units
+(Angstrom, ps, eV, e, amu).
+"""
+import os
+
+import numpy as np
+
+VDW_TYPES = {"lnjs": 1, "buck": 2, "p746": 3, "bmhs": 4, "elin": 5, "einv": 6, "surk": 7}
+VDW_NAMES = {v: k for k, v in VDW_TYPES.items()}
+VDW_NPARAM = {1: 2, 2: 3, 3: 3, 4: 5, 5: 3, 6: 3, 7: 4}          # vdw.cpp:195
+ELEC_TYPES = {"none": 0, "dir": 1, "pme": 2, "fenn": 3}
+ELEC_NAMES = {v: k for k, v in ELEC_TYPES.items()}
+TSTAT_NAMES = {0: "none", 1: "nose", 2: "radi"}
+
+AR_MASS = 39.9
+AR_EPS = 0.01006
+AR_SIGMA = 3.3952
+
+
+def fcc_positions(ncell, a, jitter, seed, offset=0.25):
+    """FCC lattice of ncell=(nx,ny,nz) conventional cells, edge a, + U(-jitter, jitter) per coordinate."""
+    nx, ny, nz = ncell
+    basis = np.array([(0, 0, 0), (.5, .5, 0), (.5, 0, .5), (0, .5, .5)], dtype=np.float64)
+    ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    cells = np.stack([ii.ravel(), jj.ravel(), kk.ravel()], axis=1).astype(np.float64)
+    pos = (cells[:, None, :] + basis[None, :, :]).reshape(-1, 3) * a + offset
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pos += rng.uniform(-jitter, jitter, size=pos.shape)
+    box = np.array([nx * a, ny * a, nz * a], dtype=np.float64)
+    pos = np.mod(pos, box)
+    pos[pos >= box] = 0.0
+    return pos, box
+
+
+def lj_case(ncell, a=5.735, jitter=0.15, seed=20240501, rc=8.5, dt=0.001, charges=None, elec="none",
+            r_real=8.5, alpha=0.4, T=85.0, tstat="none", nsteps=0, cell_list=None, vel_T=None, quantize=True,
+            radii=None, nEq=0, freqEq=1):
+    """LJ-argon box (configs C2/C3/C4 and the small parity fixtures F1-F3 of SURVEY 8d).
+
+    charges: None (one neutral species) or (qA, qB) -> two species alternating by atom index.
+    vel_T: if given, Maxwell-Boltzmann velocities at that temperature (zero net momentum);
+           default: zero velocities (`init_vel zero`).
+    quantize: round coordinates to 6 decimals so that what is written to atoms.xyz with %f is
+              exactly what the array entry points see.
+    """
+    pos, box = fcc_positions(ncell, a, jitter, seed)
+    if quantize:
+        pos = np.round(pos, 6)
+        box = np.round(box, 6)
+        pos[pos >= box] = 0.0
+    N = pos.shape[0]
+    if charges is None:
+        species = [(AR_MASS, 0.0)]
+        names = ["Ar"]
+        types = np.zeros(N, dtype=np.int32)
+        vdw = [(0, 0, VDW_TYPES["lnjs"], rc, [AR_EPS, AR_SIGMA])]
+    else:
+        species = [(AR_MASS, charges[0]), (AR_MASS, charges[1])]
+        names = ["A", "B"]
+        types = (np.arange(N) % 2).astype(np.int32)
+        vdw = [(0, 0, 1, rc, [AR_EPS, AR_SIGMA]), (0, 1, 1, rc, [AR_EPS, AR_SIGMA]), (1, 1, 1, rc, [AR_EPS, AR_SIGMA])]
+    vel = np.zeros_like(pos)
+    if vel_T:
+        kB = 1.3806488E-23 / 1.60217733E-19
+        m = AR_MASS * (1.6605402E-27 / (1.60217733E-19 * 1e-24 / 1e-20))
+        rng = np.random.Generator(np.random.PCG64(seed + 7))
+        vel = rng.normal(0.0, np.sqrt(kB * vel_T / m), size=pos.shape)
+        vel -= vel.mean(axis=0)
+    case = {
+        "box": box.tolist(), "dt": dt, "nsteps": nsteps,
+        "species": species, "names": names, "vdw": vdw, "types": types,
+        "x": pos[:, 0].copy(), "y": pos[:, 1].copy(), "z": pos[:, 2].copy(),
+        "vx": vel[:, 0].copy(), "vy": vel[:, 1].copy(), "vz": vel[:, 2].copy(),
+        "elec_type": ELEC_TYPES[elec], "rReal": r_real if elec != "none" else 0.0, "alpha": alpha if elec != "none" else 0.0,
+        "T": T, "tstat_type": {"none": 0, "nose": 1, "radi": 2}[tstat], "nEq": nEq, "freqEq": freqEq,
+        "use_clist": 1, "cell_list": cell_list if cell_list is not None else rc,
+        "center_box": 0, "init_forces": 1, "radii": radii, "seed": 12345,
+    }
+    return case
+
+
+def write_input_files(case, directory, stat=200):
+    """Write atoms.xyz / field.txt / control.txt / cuda.txt for `case` (reference grammar)."""
+    os.makedirs(directory, exist_ok=True)
+    names = case.get("names") or ["S%d" % i for i in range(len(case["species"]))]
+    N = len(case["types"])
+    with open(os.path.join(directory, "atoms.xyz"), "w") as f:
+        f.write("%d\n" % N)
+        f.write("1 %f %f %f\n" % tuple(case["box"]))
+        t = np.asarray(case["types"])
+        x, y, z = case["x"], case["y"], case["z"]
+        lines = ["%s\t%f\t%f\t%f\n" % (names[t[i]], x[i], y[i], z[i]) for i in range(N)]
+        f.writelines(lines)
+    with open(os.path.join(directory, "field.txt"), "w") as f:
+        f.write("spec %d\n" % len(case["species"]))
+        for nm, (m, q) in zip(names, case["species"]):
+            f.write("%s\t%s\t%r\t%r\t0.0\n" % (nm, nm, m, q))
+        f.write("red-ox 0\n")
+        f.write("vdw %d\n" % len(case["vdw"]))
+        for a, b, t, rc, p in case["vdw"]:
+            ps = "\t".join(repr(float(v)) for v in list(p)[:VDW_NPARAM[t]])
+            f.write("%s\t%s\t%s\t%r\t%s\n" % (names[a], names[b], VDW_NAMES[t], float(rc), ps))
+        if case.get("radii"):
+            f.write("radii %d\n" % len(case["species"]))
+            for nm, r in zip(names, case["radii"]):
+                f.write("%s\t%r\t%r\t%r\n" % (nm, r[0], r[1], r[2]))
+    with open(os.path.join(directory, "control.txt"), "w") as f:
+        f.write("timestep %r ps\n" % case["dt"])
+        f.write("nstep %d\n" % max(int(case.get("nsteps", 0)), 0))
+        f.write("nequil %d\n" % case.get("nEq", 0))
+        f.write("eqfreq %d\n" % case.get("freqEq", 1))
+        ts = TSTAT_NAMES[case.get("tstat_type", 0)]
+        f.write("temperature %r\t%s%s\n" % (float(case.get("T", 0.0)), ts, "\t0.2" if ts == "radi" else ""))
+        f.write("init_vel\tzero\n")
+        f.write("permittivity 1.0\n")
+        f.write("cell_list\t%r\n" % float(case.get("cell_list", 8.5)))
+        et = ELEC_NAMES[case.get("elec_type", 0)]
+        if et == "none":
+            f.write("elec\tnone\n")
+        elif et == "dir":
+            f.write("elec\tdir\t%r\n" % case["rReal"])
+        else:
+            f.write("elec\t%s\t%r\t%r\n" % (et, case["rReal"], case["alpha"]))
+        f.write("rdf\t8.0\t0.02\t1000000\t1000000\tnucl\n")
+        f.write("stat\t%d\n" % stat)
+    with open(os.path.join(directory, "cuda.txt"), "w") as f:
+        f.write("nstep stat 50\nnthread a 16\nnthread b 32\n")
+    return directory
+
+
+# named configurations of SURVEY.md 8(d)
+def config(name):
+    if name == "F1":      # 500-atom FCC(5^3)
+        return lj_case((5, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5)
+    if name == "F2":      # 4 000-atom probe system, rc 8.5
+        return lj_case((10, 10, 10), a=5.26, seed=12345)
+    if name == "F3":      # F2 with +-0.2 charges + Fennell
+        return lj_case((10, 10, 10), a=5.26, seed=12345, charges=(0.2, -0.2), elec="fenn")
+    if name == "C2":      # 40 000 Ar LJ
+        return lj_case((20, 20, 25), seed=20240501)
+    if name == "C3":      # 1 000 188 atoms, LJ + Fennell
+        return lj_case((63, 63, 63), seed=20240502, charges=(0.2, -0.2), elec="fenn")
+    if name == "C4":      # 1 000 188 atoms, pure LJ
+        return lj_case((63, 63, 63), seed=20240502)
+    raise KeyError(name)

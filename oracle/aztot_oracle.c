@@ -1,0 +1,725 @@
+/* TEST INFRASTRUCTURE - CPU oracle for the azTotMD per-step hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker.  The product (aztotmd_amd/) never links, imports or
+ * executes anything in oracle/.
+ *
+ * This file is a from-scratch fp64 restatement (plain C99) of the reference's serial
+ * algorithm for the path
+ *     cell-list build -> pair VdW + short-range Coulomb -> velocity Verlet (+ thermostat)
+ * Each function cites the reference file:line it follows (paths relative to
+ * /root/reference/src).  Where the serial program has no implementation (radiative
+ * thermostat, elin/einv/surk potentials) the CUDA source text is followed in fp64 and the
+ * header of the function says so.
+ *
+ * PARITY PINNING: pair functions, min-image, wrap, linked-cell table/traversal, integrator
+ * and energy bookkeeping are pinned against the reference's own compiled translation units
+ * (oracle/_ref, built by oracle/Makefile from the sources where they lie) by
+ * tests/test_oracle_vs_ref.py and by the committed fixtures in tests/golden/ that the same
+ * binary generated (tests/golden/make_golden.py).  The parser/derived-parameter chain is
+ * pinned by the known-answer table of SURVEY.md Appendix F (tests/golden/appendix_f.json).
+ * The radiative thermostat, elin/einv/surk are "parity unpinned" by the reference (it ships
+ * no CPU implementation, no tests and no outputs for them): see DESIGN.md.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- constants: const.h:11-49 */
+static const double ORC_PI = 3.14159265359;               /* const.h:11 (truncated on purpose) */
+#define ORC_E_SI 1.60217733E-19
+#define ORC_Q_SI 1.60217657E-19
+#define ORC_KB_SI 1.3806488E-23
+#define ORC_E0_SI 8.854187817E-12
+#define ORC_AMU_SI 1.6605402E-27
+#define ORC_R_SI 1.0E-10
+#define ORC_T_SI 1.0E-12
+
+static double c_m_scale(void) { double m_SI = ORC_E_SI * ORC_T_SI * ORC_T_SI / ORC_R_SI / ORC_R_SI; return ORC_AMU_SI / m_SI; }   /* const.h:27,43 */
+static double c_kB(void) { return ORC_KB_SI / (1.0 * ORC_E_SI); }                                                                 /* const.h:47 */
+static double c_Fcoul(void)
+{   /* const.h:28-29,44 */
+    double F_SI = ORC_E_SI / ORC_R_SI;
+    double Fcoul_SI = 0.25 / ORC_PI / ORC_E0_SI * ORC_Q_SI * ORC_Q_SI / ORC_R_SI / ORC_R_SI;
+    return Fcoul_SI / F_SI;
+}
+
+enum { VDW_NONE = 0, VDW_LJ = 1, VDW_BUCK = 2, VDW_746 = 3, VDW_BHM = 4, VDW_ELIN = 5, VDW_EINV = 6, VDW_SURK = 7 };  /* vdw.h:15-21 */
+enum { ELEC_NONE = 0, ELEC_DIR = 1, ELEC_EWALD = 2, ELEC_FENNEL = 3 };                                                 /* elec.h:8-12 */
+enum { TSTAT_NONE = 0, TSTAT_NOSE = 1, TSTAT_RADI = 2 };                                                               /* temperature.h:10-12 */
+#define ORC_NUVECT 3072                                                                                                /* cuTemp.h:4 */
+
+typedef struct { int type; int use_radii; double p0, p1, p2, p3, p4, r2cut; } orc_vdw;
+
+typedef struct
+{
+    int N, nSpec;
+    double la, lb, lc, ha, hb, hc, ra, rb, rc_;          /* Box: dataStruct.h:205-241 */
+    double dt;
+    int *types;
+    double *x, *y, *z, *vx, *vy, *vz, *fx, *fy, *fz;
+    /* species: dataStruct.h:244-291 */
+    double *mass, *charge, *rMass_hdt, *radA, *radB, *mxEng; int *charged; int *frozen;
+    orc_vdw *vdw;                                        /* nSpec*nSpec, type 0 = none (NULL pointer in the reference) */
+    double maxRvdw;
+    /* elec: dataStruct.h:349-366 */
+    int elec_type; double rReal, r2Real, alpha, el_scale, el_scale2, daipi2;
+    double rMax, r2Max;
+    double Ux, Uy, Uz;
+    /* thermostat + control */
+    int tstat_type; double Temp, tKin; int degFree; int nEq, freqEq;
+    int use_clist;                                       /* control.txt 'cell_list' present */
+    /* linked cells: Sim fields dataStruct.h:88-99 */
+    int nHead, cnX, cnY, cnZ, cnYZ; double clX, clY, clZ;
+    int *clist, *chead, *neig;                           /* neig[nHead*13] */
+    /* energies / counters */
+    double engVdW, engElec3, engKin, engTot, engElecField, engTemp, TempNow;
+    double mom[6];                                       /* Xn, Xp, Yn, Yp, Zn, Zp: box.cpp:230-295 */
+    long long cross[6];
+    long long nDropped;                                  /* pairs dropped by the f^2 > 1e10 rule, integrators.cpp:170 */
+    int iStep;                                           /* 1-based index of the last completed step (main.cpp:92) */
+    /* radiative thermostat state (cuStruct.h:250-255,335-339,384-385) */
+    double *U, *rad, *photons; double *uvx, *uvy, *uvz; int *pid; uint64_t seed;
+    double revLight, radiate_frac, radiate_thr, numPi;
+} orc_sys;
+
+/* ---------------------------------------------------------------- counter-based RNG (ours: SURVEY C-11/E) */
+static uint64_t mix64(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31; return z;
+}
+uint32_t orc_rng(uint64_t seed, uint64_t step, uint64_t id, uint64_t draw)
+{
+    uint64_t z = mix64(seed + 0x9E3779B97F4A7C15ULL * (step + 1));
+    z = mix64(z ^ (0xD1B54A32D192ED03ULL * (id + 1)));
+    z = mix64(z ^ (0x8CB92BA72F3D8DD7ULL * (draw + 1)));
+    return (uint32_t)(z >> 32);
+}
+#define RNG_STREAM_TABLES 0xFFFFFFFFFFFFFFF0ULL   /* "step" value reserved for table generation */
+
+/* ---------------------------------------------------------------- lifecycle */
+orc_sys *orc_create(int N, int nSpec, const double *box, const int *types,
+                    const double *x, const double *y, const double *z,
+                    const double *vx, const double *vy, const double *vz)
+{
+    orc_sys *s = (orc_sys *)calloc(1, sizeof(orc_sys));
+    s->N = N; s->nSpec = nSpec;
+    s->la = box[0]; s->lb = box[1]; s->lc = box[2];
+    /* prepare_box: box.cpp:73-86 */
+    s->ha = s->la * 0.5; s->hb = s->lb * 0.5; s->hc = s->lc * 0.5;
+    s->ra = 1.0 / s->la; s->rb = 1.0 / s->lb; s->rc_ = 1.0 / s->lc;
+    size_t nb = sizeof(double) * (size_t)N;
+    s->types = (int *)malloc(sizeof(int) * (size_t)N); memcpy(s->types, types, sizeof(int) * (size_t)N);
+    double **dst[] = { &s->x, &s->y, &s->z, &s->vx, &s->vy, &s->vz, &s->fx, &s->fy, &s->fz, &s->U, &s->rad };
+    const double *src[] = { x, y, z, vx, vy, vz, NULL, NULL, NULL, NULL, NULL };
+    for (int k = 0; k < 11; k++) { *dst[k] = (double *)calloc((size_t)N, sizeof(double)); if (src[k]) memcpy(*dst[k], src[k], nb); }
+    s->pid = (int *)malloc(sizeof(int) * (size_t)N); for (int i = 0; i < N; i++) s->pid[i] = i;
+    s->mass = (double *)calloc(nSpec, 8); s->charge = (double *)calloc(nSpec, 8); s->rMass_hdt = (double *)calloc(nSpec, 8);
+    s->radA = (double *)calloc(nSpec, 8); s->radB = (double *)calloc(nSpec, 8); s->mxEng = (double *)calloc(nSpec, 8);
+    s->charged = (int *)calloc(nSpec, sizeof(int)); s->frozen = (int *)calloc(nSpec, sizeof(int));
+    s->vdw = (orc_vdw *)calloc((size_t)nSpec * nSpec, sizeof(orc_vdw));
+    s->revLight = 3.33567e-5;      /* cuTemp.cu:225 (100x the physical 1/c: SURVEY C-19, kept) */
+    s->radiate_frac = 0.9;         /* cuTemp.cu:639 */
+    s->radiate_thr = 1e-4;         /* cuTemp.cu:747 */
+    s->numPi = 3.14159;            /* cuTemp.cu:228 */
+    s->seed = 12345;
+    return s;
+}
+
+void orc_free(orc_sys *s)
+{
+    if (!s) return;
+    free(s->types); free(s->x); free(s->y); free(s->z); free(s->vx); free(s->vy); free(s->vz);
+    free(s->fx); free(s->fy); free(s->fz); free(s->U); free(s->rad); free(s->pid);
+    free(s->mass); free(s->charge); free(s->rMass_hdt); free(s->radA); free(s->radB); free(s->mxEng);
+    free(s->charged); free(s->frozen); free(s->vdw);
+    free(s->clist); free(s->chead); free(s->neig);
+    free(s->photons); free(s->uvx); free(s->uvy); free(s->uvz);
+    free(s);
+}
+
+/* read_spec: sys_init.cpp:83-130 (mass in amu, charge in e) ; radii section sys_init.cpp:468-480 */
+void orc_set_species(orc_sys *s, int i, double mass_amu, double charge, int frozen, double radA, double radB, double mxEng)
+{
+    s->mass[i] = mass_amu * c_m_scale();
+    s->charge[i] = charge * 1.0;
+    s->charged[i] = fabs(s->charge[i]) < 1.0E-10 ? 0 : 1;
+    s->frozen[i] = frozen;
+    s->radA[i] = radA; s->radB[i] = radB; s->mxEng[i] = mxEng;
+}
+
+/* read_vdw: vdw.cpp:234-308 ; scale tables vdw.cpp:209-219 (r_scale = E_scale = 1) */
+int orc_set_vdw(orc_sys *s, int a, int b, int type, double rc, const double *p)
+{
+    orc_vdw pp; memset(&pp, 0, sizeof(pp));
+    pp.type = type;
+    if (rc > s->maxRvdw) s->maxRvdw = rc;
+    pp.r2cut = rc * rc;
+    pp.p0 = p[0]; pp.p1 = p[1]; pp.p2 = p[2]; pp.p3 = p[3]; pp.p4 = p[4];
+    switch (type)
+    {
+    case VDW_LJ:   pp.p0 *= 4; pp.p2 = 0; pp.p3 = 0; pp.p4 = 0;
+                   pp.p1 = pp.p1 * pp.p1; pp.p2 = 6 * pp.p0; break;            /* vdw.cpp:283-288 */
+    case VDW_BUCK: pp.p3 = 0; pp.p4 = 0; break;
+    case VDW_746:  pp.p3 = 0; pp.p4 = 0; break;
+    case VDW_BHM:  break;
+    case VDW_ELIN: pp.p3 = 0; pp.p4 = 0; break;
+    case VDW_EINV: pp.p3 = 0; pp.p4 = 0; break;
+    case VDW_SURK: pp.p4 = 0; pp.use_radii = 1; break;                         /* vdw.cpp:289-299 */
+    default: return 0;
+    }
+    s->vdw[a * s->nSpec + b] = pp;
+    if (type != VDW_SURK) s->vdw[b * s->nSpec + a] = pp;                       /* vdw.cpp:303-307 */
+    return 1;
+}
+
+/* read_elec elec.cpp:14-67 */
+void orc_set_elec(orc_sys *s, int type, double rReal, double alpha)
+{
+    s->elec_type = type; s->rReal = rReal; s->alpha = alpha;
+}
+
+void orc_set_control(orc_sys *s, double dt, double T, int tstat_type, int nEq, int freqEq, int use_clist,
+                     double Ux, double Uy, double Uz, uint64_t seed)
+{
+    s->dt = dt; s->Temp = T; s->tstat_type = tstat_type; s->nEq = nEq; s->freqEq = freqEq; s->use_clist = use_clist;
+    s->Ux = Ux; s->Uy = Uy; s->Uz = Uz; s->seed = seed;
+}
+
+/* ---------------------------------------------------------------- linked cells: cell_list.cpp:24-134 */
+static int cell_wrap_index(int x, int y, int z, int mx, int my, int mz)
+{   /* cell_index: cell_list.cpp:22-46 */
+    int i = x, j = y, k = z;
+    if (i >= mx) i = 0; else if (i < 0) i = mx - 1;
+    if (j >= my) j = 0; else if (j < 0) j = my - 1;
+    if (k >= mz) k = 0; else if (k < 0) k = mz - 1;
+    return i * my * mz + j * mz + k;
+}
+
+static int init_clist(orc_sys *s, double rCut)
+{   /* init_clist: cell_list.cpp:48-134.  Only the "all dimensions full" geometry (:107-134) is restated;
+       slab/stack geometries (:138-262) fall back to all-pairs, which visits the same pairs. */
+    int nX = (int)floor(s->la / rCut), nY = (int)floor(s->lb / rCut), nZ = (int)floor(s->lc / rCut);
+    if (nX == 0) nX = 1; if (nY == 0) nY = 1; if (nZ == 0) nZ = 1;
+    s->cnX = nX; s->cnY = nY; s->cnZ = nZ; s->nHead = 0;
+    if ((nX < 4) && (nY < 4) && (nZ < 4)) return 0;                              /* :74-75 */
+    if (!((nX > 2) && (nY > 2) && (nZ > 2))) return 0;
+    int nYZ = nY * nZ; s->cnYZ = nYZ;
+    s->clX = s->la / nX; s->clY = s->lb / nY; s->clZ = s->lc / nZ;
+    s->nHead = nX * nY * nZ;
+    s->clist = (int *)malloc(sizeof(int) * (size_t)s->N);
+    s->chead = (int *)malloc(sizeof(int) * (size_t)s->nHead);
+    s->neig = (int *)malloc(sizeof(int) * 13 * (size_t)s->nHead);
+    static const int off[13][3] = {                                            /* order of :119-133 */
+        { 1, 1, 1 }, { 1, 0, 1 }, { 1, -1, 1 }, { 0, 1, 1 }, { 0, 0, 1 }, { 0, -1, 1 }, { -1, 1, 1 }, { -1, 0, 1 }, { -1, -1, 1 },
+        { 1, 1, 0 }, { 1, 0, 0 }, { 1, -1, 0 }, { 0, 1, 0 } };
+    for (int i = 0; i < nX; i++) for (int j = 0; j < nY; j++) for (int k = 0; k < nZ; k++)
+    {
+        int ci = i * nYZ + j * nZ + k;
+        for (int m = 0; m < 13; m++) s->neig[ci * 13 + m] = cell_wrap_index(i + off[m][0], j + off[m][1], k + off[m][2], nX, nY, nZ);
+    }
+    return s->nHead;
+}
+
+int orc_cells(const orc_sys *s, int *dims) { dims[0] = s->cnX; dims[1] = s->cnY; dims[2] = s->cnZ; return s->nHead; }
+const int *orc_neig_table(const orc_sys *s) { return s->neig; }
+
+/* ---------------------------------------------------------------- photon / unit-vector tables */
+static double prob4(double x, double y, double theta)
+{   /* temperature.cpp:18-26 */
+    const double r24 = 1.0 / 24.0, r6 = 1.0 / 6.0;
+    double ty = theta * y, ty2 = ty * ty;
+    return (1 - x) * exp(y * theta) - (r24 * ty2 * ty2 + r6 * ty2 * ty + 0.5 * ty * ty + ty + 1);
+}
+
+static double rand01_ctr(uint64_t seed, uint64_t id, uint64_t *draw)
+{   /* rand01: utils.cpp:197-201 (1e-4 resolution kept), libc rand() replaced by the counter RNG */
+    uint32_t r = orc_rng(seed, RNG_STREAM_TABLES, id, (*draw)++);
+    return (double)(r % 10000) / 10000;
+}
+
+void orc_photon_engs(int n, double *engs, double T, uint64_t seed)
+{   /* photon_engs: temperature.cpp:28-89 */
+    const double eps = 1e-3; const int limit = 20;
+    double theta = 1.0 / (c_kB() * T);
+    for (int i = 0; i < n; i++)
+    {
+        uint64_t draw = 0;
+        double a = 0.0, b = 1.0, x, ra, rb, y, r;
+        do { x = rand01_ctr(seed, (uint64_t)i, &draw); ra = prob4(x, 0.0, theta); rb = prob4(x, 1.0, theta); } while (ra * rb > 0);
+        y = 0.5; r = prob4(x, y, theta);
+        int k = 0;
+        while ((r > eps) || (r < -eps))
+        {
+            if ((r * ra) < 0) { b = y; y = 0.5 * (a + y); } else { a = y; y = 0.5 * (y + b); }
+            r = prob4(x, y, theta);
+            k++;
+            if (k >= limit) { if (i > 0) y = engs[i - 1]; break; }   /* :76-80 ; i == 0 would read engs[-1] (SURVEY C-21): keep y */
+        }
+        engs[i] = y;
+    }
+}
+
+void orc_unit_vectors(double *ux, double *uy, double *uz)
+{   /* temperature.cpp:165-223: 32 phi x 16 theta, +/- pairs, three axis permutations */
+    const int nTh = 16, nPhi = 32; int k = 0;
+    const double twopi = 2.0 * ORC_PI;
+    for (int perm = 0; perm < 3; perm++)
+        for (int i = 0; i < nPhi; i++)
+        {
+            double phi = (double)i / nPhi * twopi;
+            for (int j = 0; j < nTh; j++)
+            {
+                double theta = (double)j / nTh * ORC_PI;
+                double st = sin(theta), ct = cos(theta), sp = sin(phi), cp = cos(phi);
+                double a = cp * ct, b = sp * ct, c = st;     /* (cos t cos p, cos t sin p, sin t) */
+                double X, Y, Z;
+                if (perm == 0) { X = a; Y = b; Z = c; }        /* :174-178 */
+                else if (perm == 1) { X = a; Z = b; Y = c; }   /* :192-196 */
+                else { Z = a; Y = b; X = c; }                  /* :210-214 */
+                ux[k] = X; uy[k] = Y; uz[k] = Z;
+                ux[k + 1] = -X; uy[k + 1] = -Y; uz[k + 1] = -Z;
+                k += 2;
+            }
+        }
+}
+
+/* ---------------------------------------------------------------- init_md derived parameters: sys_init.cpp:1053-1112 */
+int orc_prepare(orc_sys *s)
+{
+    int any_charged = 0;
+    for (int i = 0; i < s->nSpec; i++) if (s->charge[i] != 0.0) any_charged = 1;      /* sys_init.cpp:210 */
+    if (!any_charged && s->elec_type) s->elec_type = ELEC_NONE;                         /* elec.cpp:52-56 */
+    if (s->elec_type == ELEC_NONE && 0) s->rReal = 0.0;
+    s->r2Real = s->rReal * s->rReal;
+    if (s->elec_type == ELEC_FENNEL)
+    {   /* prepare_elec: elec.cpp:399-405 */
+        double sqrtpi = sqrt(ORC_PI);
+        double aRc = s->alpha * s->rReal;
+        s->daipi2 = 2 * s->alpha / sqrtpi;
+        s->el_scale = erfc(aRc) / s->rReal;
+        s->el_scale2 = erfc(aRc) / s->r2Real + s->daipi2 * exp(-aRc * aRc) / s->rReal;
+    }
+    for (int i = 0; i < s->nSpec; i++) s->rMass_hdt[i] = 0.5 * s->dt / s->mass[i];    /* :1056-1057 */
+    s->rMax = 0.0;
+    if (s->elec_type) s->rMax = s->rReal; else s->rMax = s->maxRvdw;                  /* :1060-1071 */
+    s->r2Max = s->rMax * s->rMax;
+    s->degFree = 3 * s->N; if (s->tstat_type) s->degFree--;                             /* :1099-1103 */
+    s->tKin = 0.5 * s->Temp * c_kB() * s->degFree;                                      /* :1106 */
+    if (s->use_clist) init_clist(s, s->rMax);                                           /* :1130-1133 */
+    if (s->tstat_type == TSTAT_RADI)
+    {   /* read_tstat temperature.cpp:113-245 ; init_cuda_tstat cuTemp.cu:25-60 */
+        s->photons = (double *)malloc(8 * (size_t)s->N);
+        orc_photon_engs(s->N, s->photons, s->Temp, s->seed);
+        s->uvx = (double *)malloc(8 * ORC_NUVECT); s->uvy = (double *)malloc(8 * ORC_NUVECT); s->uvz = (double *)malloc(8 * ORC_NUVECT);
+        orc_unit_vectors(s->uvx, s->uvy, s->uvz);
+        for (int i = 0; i < s->N; i++)
+        {
+            uint64_t draw = 1000;
+            s->U[i] = 0.0;
+            s->rad[i] = 0.577 + rand01_ctr(s->seed, (uint64_t)i, &draw) * 0.0001;      /* cuTemp.cu:41 */
+        }
+    }
+    return 1;
+}
+
+/* center_box: box.cpp:337-384 (serial path only, sys_init.cpp:1145) */
+void orc_center_box(orc_sys *s)
+{
+    double mxx = 0, mxy = 0, mxz = 0, mnx = s->la, mny = s->lb, mnz = s->lc;
+    for (int i = 0; i < s->N; i++)
+    {
+        if (s->x[i] > mxx) mxx = s->x[i]; if (s->x[i] < mnx) mnx = s->x[i];
+        if (s->y[i] > mxy) mxy = s->y[i]; if (s->y[i] < mny) mny = s->y[i];
+        if (s->z[i] > mxz) mxz = s->z[i]; if (s->z[i] < mnz) mnz = s->z[i];
+    }
+    double dx = 0.5 * (mxx - mnx) - s->ha, dy = 0.5 * (mxy - mny) - s->hb, dz = 0.5 * (mxz - mnz) - s->hc;
+    for (int i = 0; i < s->N; i++) { s->x[i] -= dx; s->y[i] -= dy; s->z[i] -= dz; }
+}
+
+/* ---------------------------------------------------------------- pair potentials */
+/* Returns f = -(1/r) dU/dr and adds U to *eng.  r is "0 = unknown" as in the reference. */
+static double vdw_fer(const orc_vdw *v, double r2, double *r, double radi, double radj, double *eng)
+{
+    switch (v->type)
+    {
+    case VDW_LJ:
+    {   /* fer_lj: vdw.cpp:16-26 */
+        double r2i = 1.0 / r2;
+        double sr2 = v->p1 * r2i;
+        double sr6 = sr2 * sr2 * sr2;
+        *eng += v->p0 * sr6 * (sr6 - 1.0);
+        return v->p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
+    }
+    case VDW_BUCK:
+    {   /* fer_buckingham: vdw.cpp:60-70 */
+        double r2i = 1.0 / r2, r4i = r2i * r2i;
+        if (*r == 0.0) *r = sqrt(r2);
+        *eng += v->p0 * exp(-*r / v->p1) - v->p2 * r4i * r2i;
+        return v->p0 * exp(-*r / v->p1) / *r / v->p1 - 6.0 * v->p2 * r4i * r4i;
+    }
+    case VDW_BHM:
+    {   /* fer_bhm: vdw.cpp:102-112 */
+        double r2i = 1.0 / r2, r4i = r2i * r2i;
+        if (*r == 0.0) *r = sqrt(r2);
+        *eng += v->p0 * exp(v->p1 * (v->p2 - *r)) - v->p3 * r4i * r2i - v->p4 * r4i * r4i;
+        return v->p0 * v->p1 * exp(v->p1 * (v->p2 - *r)) / *r - 6.0 * v->p3 * r4i * r4i - 8.0 * v->p4 * r4i * r4i * r2i;
+    }
+    case VDW_746:
+    {   /* fer_746: vdw.cpp:144-157 */
+        double r2i = 1.0 / r2, r4i = r2i * r2i, ri;
+        if (*r == 0.0) ri = sqrt(r2i); else ri = 1.0 / *r;
+        *eng += r4i * (v->p0 * r2i * ri - v->p1 - v->p2 * r2i);
+        return r4i * r2i * (7.0 * v->p0 * r2i * ri - 4.0 * v->p1 - 6.0 * v->p2 * r2i);
+    }
+    case VDW_ELIN:
+    {   /* cu_fer_elin: cuVdW.cu:162-171 (fp64 here; no serial implementation, vdw.cpp:204-207) */
+        if (*r == 0.0) *r = sqrt(r2);
+        *eng += v->p0 * exp(-*r / v->p1) + v->p2 * *r;
+        return v->p0 * exp(-*r / v->p1) / *r / v->p1 - v->p2 / *r;
+    }
+    case VDW_EINV:
+    {   /* cu_fer_einv: cuVdW.cu:200-208 */
+        if (*r == 0.0) *r = sqrt(r2);
+        *eng += v->p0 * exp(-*r / v->p1) - v->p2 / *r;
+        return v->p0 * exp(-*r / v->p1) / *r / v->p1 - v->p2 / *r / r2;
+    }
+    case VDW_SURK:
+    {   /* surk_pot: cuVdW.cu:236-257 */
+        double c2ir_sum = v->p1 / (v->p2 * radi + v->p3 * radj);
+        double r_prod = radi * radj;
+        double C1ab2 = r_prod * r_prod * v->p0;
+        double r6 = r2 * r2 * r2;
+        double rr = sqrt(r2);
+        double ir6 = 1.0 / r6, ir = 1.0 / rr;
+        *eng += r_prod * ir6 * (C1ab2 * ir - c2ir_sum);
+        return r_prod * ir6 / r2 * (7.0 * C1ab2 * ir - 6.0 * c2ir_sum);
+    }
+    }
+    return 0.0;
+}
+
+static void pair_elec(orc_sys *s, int it, int jt, double r2, double r, double *force)
+{   /* r is passed BY VALUE in the reference (elec.h:16) so VdW still sees r = 0 afterwards */
+    if (s->elec_type == ELEC_NONE) return;                                  /* none_elec: elec.cpp:447 */
+    if (!s->charged[it] || !s->charged[jt]) return;
+    if (s->elec_type == ELEC_DIR)
+    {   /* direct_coul: elec.cpp:415-428 */
+        double kqq = s->charge[it] * s->charge[jt] * c_Fcoul();
+        if (r == 0) r = sqrt(r2);
+        s->engElec3 += kqq / r;
+        *force += kqq / r / r2;
+    }
+    else if (s->elec_type == ELEC_FENNEL)
+    {   /* fennel: elec.cpp:430-444 */
+        if (r == 0) r = sqrt(r2);
+        double ir = 1.0 / r;
+        double kqq = s->charge[it] * s->charge[jt] * c_Fcoul();
+        double ar = s->alpha * r;
+        double erfcar = erfc(ar);
+        s->engElec3 += kqq * (erfcar * ir - s->el_scale + s->el_scale2 * (r - s->rReal));
+        *force += kqq * ir * ((erfcar / r2 + s->daipi2 * exp(-ar * ar) * ir) - s->el_scale2);
+    }
+    else if (s->elec_type == ELEC_EWALD)
+    {   /* direct_ewald -> coul_iter: elec.cpp:408-413, 344-369 (real-space part only) */
+        double kqq = s->charge[it] * s->charge[jt] * c_Fcoul();
+        if (r == 0) r = sqrt(r2);
+        double ar = s->alpha * r, erfcar = erfc(ar);
+        s->engElec3 += kqq * erfcar / r;
+        *force += kqq / r / r2 * (erfcar + 2 * ar / sqrt(ORC_PI) * exp(-ar * ar));
+    }
+}
+
+/* known-answer entry points for the unit tests */
+double orc_vdw_pair(int type, double rc, const double *p, double r2, double radi, double radj, double *eng_out)
+{
+    orc_sys *s = orc_create(0, 1, (double[]){ 1, 1, 1 }, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+    orc_set_vdw(s, 0, 0, type, rc, p);
+    double r = 0.0, e = 0.0;
+    double f = vdw_fer(&s->vdw[0], r2, &r, radi, radj, &e);
+    *eng_out = e; orc_free(s); return f;
+}
+double orc_coul_pair(int type, double rReal, double alpha, double qi, double qj, double r2, double *eng_out)
+{
+    orc_sys *s = orc_create(0, 2, (double[]){ 1, 1, 1 }, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+    orc_set_species(s, 0, 1.0, qi, 0, 0, 0, 0); orc_set_species(s, 1, 1.0, qj, 0, 0, 0, 0);
+    orc_set_elec(s, type, rReal, alpha); s->dt = 1; orc_prepare(s);
+    double f = 0.0; pair_elec(s, 0, 1, r2, 0.0, &f);
+    *eng_out = s->engElec3; orc_free(s); return f;
+}
+void orc_elec_consts(const orc_sys *s, double *out) { out[0] = s->el_scale; out[1] = s->el_scale2; out[2] = s->daipi2; out[3] = s->rMax; out[4] = s->tKin; out[5] = c_kB(); out[6] = c_m_scale(); out[7] = c_Fcoul(); }
+
+/* ---------------------------------------------------------------- box */
+static void delta_periodic(const orc_sys *s, double *dx, double *dy, double *dz)
+{   /* box.cpp:180-207 */
+    if (*dx > s->ha) *dx -= s->la; else if (*dx < -s->ha) *dx += s->la;
+    if (*dy > s->hb) *dy -= s->lb; else if (*dy < -s->hb) *dy += s->lb;
+    if (*dz > s->hc) *dz -= s->lc; else if (*dz < -s->hc) *dz += s->lc;
+}
+
+static void put_periodic(orc_sys *s, int i)
+{   /* box.cpp:230-295.  One deviation, documented (SURVEY C-6): a coordinate that lands on
+       x >= L after the shift (incl. the serial path's surviving x == L) is set to 0 as the
+       GPU path does (cuMDfunc.cu:64-69), so the cell index stays in range. */
+    double m = s->mass[s->types[i]];
+    if (s->x[i] < 0) { s->x[i] += ((int)(-s->x[i] * s->ra) + 1) * s->la; s->cross[0]++; s->mom[0] += m * (-s->vx[i]); }
+    else if (s->x[i] > s->la) { s->x[i] -= ((int)(s->x[i] * s->ra)) * s->la; s->cross[1]++; s->mom[1] += m * s->vx[i]; }
+    if (s->y[i] < 0) { s->y[i] += ((int)(-s->y[i] * s->rb) + 1) * s->lb; s->cross[2]++; s->mom[2] += m * (-s->vy[i]); }
+    else if (s->y[i] > s->lb) { s->y[i] -= ((int)(s->y[i] * s->rb)) * s->lb; s->cross[3]++; s->mom[3] += m * s->vy[i]; }
+    if (s->z[i] < 0) { s->z[i] += ((int)(-s->z[i] * s->rc_) + 1) * s->lc; s->cross[4]++; s->mom[4] += m * (-s->vz[i]); }
+    else if (s->z[i] > s->lc) { s->z[i] -= ((int)(s->z[i] * s->rc_)) * s->lc; s->cross[5]++; s->mom[5] += m * s->vz[i]; }
+    if (s->x[i] >= s->la) s->x[i] = 0.0;
+    if (s->y[i] >= s->lb) s->y[i] = 0.0;
+    if (s->z[i] >= s->lc) s->z[i] = 0.0;
+}
+
+/* ---------------------------------------------------------------- integrators.cpp */
+static void clear_force(orc_sys *s)
+{   /* clear_force: integrators.cpp:17-39 with the GPU path's 3-component field (cuMDfunc.cu:478);
+       the serial 'shiftX' special-purpose push (:33-36) is out of scope */
+    for (int i = 0; i < s->N; i++)
+    {
+        double q = s->charge[s->types[i]];
+        s->fx[i] = -q * s->Ux; s->fy[i] = -q * s->Uy; s->fz[i] = -q * s->Uz;
+    }
+}
+
+static void reset_chars(orc_sys *s) { s->engVdW = 0.0; s->engElec3 = 0.0; s->engElecField = 0.0; s->engTemp = 0.0; }   /* integrators.cpp:42-60 */
+
+static void pair_inter(orc_sys *s, int i, int j)
+{   /* pair_inter: integrators.cpp:139-185 ; sqr_distance_proj box.cpp:327-335 */
+    double dx = s->x[i] - s->x[j], dy = s->y[i] - s->y[j], dz = s->z[i] - s->z[j];
+    delta_periodic(s, &dx, &dy, &dz);
+    double r2 = dx * dx + dy * dy + dz * dz;
+    if (r2 <= s->r2Max)
+    {
+        int it = s->types[i], jt = s->types[j];
+        double r = 0.0, f = 0.0;
+        pair_elec(s, it, jt, r2, r, &f);
+        const orc_vdw *v = &s->vdw[it * s->nSpec + jt];
+        if (v->type != VDW_NONE)
+            if (r2 <= v->r2cut)
+                f += vdw_fer(v, r2, &r, s->rad[i], s->rad[j], &s->engVdW);
+        if (f * f > 1e10) { s->nDropped++; return; }                        /* :170-174 */
+        s->fx[i] += f * dx; s->fx[j] -= f * dx;
+        s->fy[i] += f * dy; s->fy[j] -= f * dy;
+        s->fz[i] += f * dz; s->fz[j] -= f * dz;
+    }
+}
+
+static void all_pairs(orc_sys *s)
+{   /* integrators.cpp:278-289 */
+    for (int i = 0; i < s->N - 1; i++) for (int j = i + 1; j < s->N; j++) pair_inter(s, i, j);
+}
+
+static void cell_list_forces(orc_sys *s)
+{   /* cell_list: integrators.cpp:238-276 */
+    for (int iC = 0; iC < s->nHead; iC++)
+    {
+        int i = s->chead[iC];
+        while (i >= 0)
+        {
+            int j = s->clist[i];
+            while (j >= 0) { pair_inter(s, i, j); j = s->clist[j]; }
+            for (int jC = 0; jC < 13; jC++)
+            {
+                j = s->chead[s->neig[iC * 13 + jC]];
+                while (j >= 0) { pair_inter(s, i, j); j = s->clist[j]; }
+            }
+            i = s->clist[i];
+        }
+    }
+}
+
+static void build_clist(orc_sys *s)
+{   /* the binning half of integrate1_clst: integrators.cpp:343-345, 368-371 ; cell_index_sim cell_list.cpp:12-20 */
+    for (int c = 0; c < s->nHead; c++) s->chead[c] = -1;
+    for (int i = 0; i < s->N; i++)
+    {
+        int a = (int)(s->x[i] / s->clX), b = (int)(s->y[i] / s->clY), c3 = (int)(s->z[i] / s->clZ);
+        int c = a * s->cnYZ + b * s->cnZ + c3;
+        s->clist[i] = s->chead[c]; s->chead[c] = i;
+    }
+}
+
+static void integrate1(orc_sys *s)
+{   /* integrate1 / integrate1_clst: integrators.cpp:292-376 ; frozen species as cuMDfunc.cu:415-420 */
+    double tSt = s->dt;
+    if (s->nHead) for (int c = 0; c < s->nHead; c++) s->chead[c] = -1;
+    for (int i = 0; i < s->N; i++)
+    {
+        int t = s->types[i];
+        double rM = s->rMass_hdt[t], q = s->charge[t];
+        s->vx[i] += rM * s->fx[i]; s->vy[i] += rM * s->fy[i]; s->vz[i] += rM * s->fz[i];
+        if (!s->frozen[t]) { s->x[i] += s->vx[i] * tSt; s->y[i] += s->vy[i] * tSt; s->z[i] += s->vz[i] * tSt; }
+        put_periodic(s, i);
+        if (s->nHead)
+        {
+            int a = (int)(s->x[i] / s->clX), b = (int)(s->y[i] / s->clY), c3 = (int)(s->z[i] / s->clZ);
+            int c = a * s->cnYZ + b * s->cnZ + c3;
+            s->clist[i] = s->chead[c]; s->chead[c] = i;
+        }
+        s->engElecField += q * (s->x[i] * s->Ux + s->y[i] * s->Uy + s->z[i] * s->Uz);   /* :374 ; cuMDfunc.cu:476 */
+    }
+}
+
+static void integrate2(orc_sys *s, int tScale)
+{   /* integrate2: integrators.cpp:486-531 ; scaling rule: serial :511-522, with the radiative
+       factor c = 0.25 and the engKin == 0 guard of temp_scale (cuTemp.cu:84-94,109-113) */
+    double tempA = 0.0;
+    for (int i = 0; i < s->N; i++)
+    {
+        int t = s->types[i]; double rM = s->rMass_hdt[t];
+        s->vx[i] += rM * s->fx[i]; s->vy[i] += rM * s->fy[i]; s->vz[i] += rM * s->fz[i];
+        tempA += (s->vx[i] * s->vx[i] + s->vy[i] * s->vy[i] + s->vz[i] * s->vz[i]) * s->mass[t];
+    }
+    s->engKin = 0.5 * tempA;
+    if (tScale && s->engKin != 0.0)
+    {
+        double c = (s->tstat_type == TSTAT_RADI) ? 0.25 : 1.0;
+        double k = sqrt(c * s->tKin / s->engKin);
+        for (int i = 0; i < s->N; i++) { s->vx[i] *= k; s->vy[i] *= k; s->vz[i] *= k; }
+        s->engKin = s->tKin;
+    }
+}
+
+static void calc_chars(orc_sys *s)
+{   /* calc_chars: integrators.cpp:63-73 (engElec1/2, engBond, engAngle, engOwn are 0 on this path) */
+    s->TempNow = 2.0 * s->engKin * (double)(1.0 / s->degFree) * (1.0 / c_kB());
+    s->engTot = s->engElecField + s->engVdW + s->engElec3 + s->engKin;
+}
+
+/* ---------------------------------------------------------------- radiative thermostat (cuTemp.cu, fp64 restatement) */
+static void get_angled_vector(const double v[3], double cos_phi, double theta, double out[3])
+{   /* get_angled_vector: cuTemp.cu:395-453 */
+    double l1 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    double v1[3] = { v[0] / l1, v[1] / l1, v[2] / l1 }, v2[3], v3[3];
+    if (v1[0] != 0.0) { v2[1] = 1.0; v2[2] = 1.0; v2[0] = -(v1[1] * v2[1] + v1[2] * v2[2]) / v1[0]; }
+    else if (v1[1] != 0.0) { v2[0] = 1.0; v2[2] = 1.0; v2[1] = -(v1[2] * v2[2]) / v1[1]; }
+    else { v2[0] = 1.0; v2[1] = 0.0; v2[2] = 0.0; }
+    v3[0] = v1[1] * v2[2] - v1[2] * v2[1];
+    v3[1] = -v1[0] * v2[2] + v1[2] * v2[0];
+    v3[2] = v1[0] * v2[1] - v1[1] * v2[0];
+    double l2 = sqrt(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2]);
+    double l3 = sqrt(v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2]);
+    for (int k = 0; k < 3; k++) { v2[k] /= l2; v3[k] /= l3; }
+    double sinPhi = sqrt(1 - cos_phi * cos_phi), sinTh = sin(theta), cosTh = cos(theta);
+    for (int k = 0; k < 3; k++) out[k] = v1[k] * cos_phi + sinPhi * (cosTh * v2[k] + sinTh * v3[k]);
+}
+
+static void tstat_radi(orc_sys *s, uint64_t step)
+{   /* tstat_radi9: cuTemp.cu:689-773 with the fixes listed in SURVEY Appendix C-9..C-12 / E */
+    for (int i = 0; i < s->N; i++)
+    {
+        uint64_t id = (uint64_t)s->pid[i];
+        double m = s->mass[s->types[i]];
+        double pe = s->photons[(id + step) % (uint64_t)s->N];                 /* C-12 restated */
+        /* draw 0 is taken and discarded in the reference (:738) */
+        {   /* adsorb_rand_photon: cuTemp.cu:484-507 */
+            uint32_t rnd = orc_rng(s->seed, step, id, 1) % ORC_NUVECT;       /* rand_uvect :230-234 */
+            double v02 = s->vx[i] * s->vx[i] + s->vy[i] * s->vy[i] + s->vz[i] * s->vz[i];
+            double ermc = pe * s->revLight / m;
+            s->vx[i] += ermc * s->uvx[rnd]; s->vy[i] += ermc * s->uvy[rnd]; s->vz[i] += ermc * s->uvz[rnd];
+            double v12 = s->vx[i] * s->vx[i] + s->vy[i] * s->vy[i] + s->vz[i] * s->vz[i];
+            s->U[i] += pe + 0.5 * m * (v02 - v12);
+        }
+        if (s->U[i] > s->radiate_thr)
+        {   /* radiate_photon3: cuTemp.cu:631-685 */
+            double u0 = s->U[i];
+            double v[3] = { s->vx[i], s->vy[i], s->vz[i] };
+            double v02 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], v0 = sqrt(v02);
+            double ph = s->radiate_frac * u0;
+            double ermc = ph * s->revLight / m;
+            double d[3];
+            if (v0 == 0.0)
+            {   /* direction undefined in the reference; use a preset unit vector */
+                uint32_t rnd = orc_rng(s->seed, step, id, 2) % ORC_NUVECT;
+                d[0] = s->uvx[rnd]; d[1] = s->uvy[rnd]; d[2] = s->uvz[rnd];
+            }
+            else
+            {
+                double ermcv0 = ermc / v0;
+                if (ermcv0 >= 1.0) { d[0] = -v[0] / v0; d[1] = -v[1] / v0; d[2] = -v[2] / v0; }   /* C-10 fix: cos_phi = -1 */
+                else
+                {
+                    uint32_t r1 = orc_rng(s->seed, step, id, 2) % 2048;
+                    double cos_phi = (double)r1 / 1024.0 * (1.0 - ermcv0);
+                    cos_phi -= 1.0;
+                    uint32_t r2 = orc_rng(s->seed, step, id, 3) % 2048;
+                    double theta = (double)r2 / 1024.0 * s->numPi;
+                    get_angled_vector(v, cos_phi, theta, d);
+                }
+            }
+            s->vx[i] += ermc * d[0]; s->vy[i] += ermc * d[1]; s->vz[i] += ermc * d[2];
+            double v12 = s->vx[i] * s->vx[i] + s->vy[i] * s->vy[i] + s->vz[i] * s->vz[i];
+            s->U[i] -= (ph + 0.5 * m * (v12 - v02));
+        }
+        {   /* radius: cuTemp.cu:757-759 */
+            int tp = s->types[i];
+            double restrE = s->U[i] < s->mxEng[tp] ? s->U[i] : s->mxEng[tp];
+            s->rad[i] = s->radA[tp] / (s->radB[tp] - restrE);
+        }
+        s->engTemp += s->U[i];
+    }
+}
+
+/* ---------------------------------------------------------------- public stepping API */
+/* mode 0: all pairs (integrators.cpp:278), 1: linked cells (integrators.cpp:238; falls back to 0 if no table) */
+void orc_forces(orc_sys *s, int mode)
+{
+    reset_chars(s);
+    clear_force(s);
+    if (mode == 1 && s->nHead) { build_clist(s); cell_list_forces(s); } else all_pairs(s);
+}
+
+void orc_step(orc_sys *s, int nsteps)
+{   /* loop body of main.cpp:89-142 ; thermostat placement as main.cu:370-382 */
+    for (int n = 0; n < nsteps; n++)
+    {
+        s->iStep++;
+        reset_chars(s);
+        integrate1(s);
+        clear_force(s);
+        if (s->nHead) cell_list_forces(s); else all_pairs(s);
+        int tScale = (s->iStep <= s->nEq) && s->freqEq > 0 && ((s->iStep % s->freqEq) == 0);   /* main.cpp:110-119 */
+        integrate2(s, tScale);
+        if (s->tstat_type == TSTAT_RADI) tstat_radi(s, (uint64_t)s->iStep);
+        calc_chars(s);
+    }
+}
+
+/* stage entry points (for kernel-by-kernel parity tests) */
+void orc_stage_integrate1(orc_sys *s) { reset_chars(s); integrate1(s); }
+void orc_stage_integrate2(orc_sys *s, int tScale) { integrate2(s, tScale); calc_chars(s); }
+void orc_stage_tstat(orc_sys *s, long long step) { s->engTemp = 0.0; tstat_radi(s, (uint64_t)step); }
+
+void orc_get_state(const orc_sys *s, double *x, double *y, double *z, double *vx, double *vy, double *vz,
+                   double *fx, double *fy, double *fz, double *U, double *rad)
+{
+    size_t nb = 8 * (size_t)s->N;
+    if (x) memcpy(x, s->x, nb); if (y) memcpy(y, s->y, nb); if (z) memcpy(z, s->z, nb);
+    if (vx) memcpy(vx, s->vx, nb); if (vy) memcpy(vy, s->vy, nb); if (vz) memcpy(vz, s->vz, nb);
+    if (fx) memcpy(fx, s->fx, nb); if (fy) memcpy(fy, s->fy, nb); if (fz) memcpy(fz, s->fz, nb);
+    if (U) memcpy(U, s->U, nb); if (rad) memcpy(rad, s->rad, nb);
+}
+void orc_set_vel(orc_sys *s, const double *vx, const double *vy, const double *vz)
+{ size_t nb = 8 * (size_t)s->N; memcpy(s->vx, vx, nb); memcpy(s->vy, vy, nb); memcpy(s->vz, vz, nb); }
+void orc_set_forces(orc_sys *s, const double *fx, const double *fy, const double *fz)
+{ size_t nb = 8 * (size_t)s->N; memcpy(s->fx, fx, nb); memcpy(s->fy, fy, nb); memcpy(s->fz, fz, nb); }
+void orc_set_thermo(orc_sys *s, const double *U, const double *rad)
+{ size_t nb = 8 * (size_t)s->N; if (U) memcpy(s->U, U, nb); if (rad) memcpy(s->rad, rad, nb); }
+const double *orc_photons(const orc_sys *s) { return s->photons; }
+
+/* out[0..15]: engVdW, engElec3, engKin, engTot, engElecField, engTemp, Temp, mom[6], nDropped, iStep, tKin */
+void orc_get_stats(const orc_sys *s, double *out)
+{
+    out[0] = s->engVdW; out[1] = s->engElec3; out[2] = s->engKin; out[3] = s->engTot; out[4] = s->engElecField;
+    out[5] = s->engTemp; out[6] = s->TempNow;
+    for (int k = 0; k < 6; k++) out[7 + k] = s->mom[k];
+    out[13] = (double)s->nDropped; out[14] = (double)s->iStep; out[15] = s->tKin;
+}
+void orc_get_cross(const orc_sys *s, long long *out) { for (int k = 0; k < 6; k++) out[k] = s->cross[k]; }
