@@ -1,0 +1,89 @@
+// Device-side state of one rank: the MI355X-native counterpart of the reference's cudaMD
+// (cuStruct.h:188-423).  cudaMD is kept as the *field inventory*; the byte layout is ours:
+// fp64 structure-of-arrays (the serial path's precision, dataStruct.h:309-311) so that every
+// per-atom stream is a unit-stride 8-byte access, double-buffered for the per-step counting sort.
+#pragma once
+#include <cstdint>
+
+namespace aztot {
+
+constexpr int kSpecCap = 16;      // >= MX_SPEC (defines.h:14)
+
+// per-atom arrays (one "buffer"; two of them ping-pong through the sort)
+struct AtomArrays
+{
+    double *x, *y, *z;            // cudaMD::xyz   (cuStruct.h:195)
+    double *vx, *vy, *vz;         // cudaMD::vls   (cuStruct.h:196)
+    double *fx, *fy, *fz;         // cudaMD::frs   (cuStruct.h:197)
+    double *U, *rad;              // cudaMD::engs, radii (cuStruct.h:384-385)
+    int32_t *type;                // cudaMD::types (cuStruct.h:199)
+    int32_t *id;                  // persistent atom id (ours: stable key for RNG / output order / determinism)
+};
+
+// species table, small enough to travel in the kernel-argument segment (scalar loads, no pointer chasing)
+struct SpecTable                  // cudaSpec, cuStruct.h:10-47
+{
+    double mass[kSpecCap], charge[kSpecCap], rMhdt[kSpecCap];
+    double radA[kSpecCap], radB[kSpecCap], mxEng[kSpecCap];
+    int32_t charged[kSpecCap], frozen[kSpecCap];
+};
+
+struct DevPot                     // cudaVdW, cuStruct.h:50-63, without the device function pointers
+{
+    int32_t type, use_radii;
+    double p0, p1, p2, p3, p4, r2cut;
+};
+
+// uniform parameters of the step (kernel argument, by value)
+struct StepParams
+{
+    int32_t nOwned;               // atoms this rank integrates
+    int32_t nTotal;               // owned + ghost atoms resident in the arrays (== nOwned on one GPU)
+    int32_t nSpec;
+    int32_t single_lj;            // fast path: one species, LJ only, no Coulomb
+    double L[3], invL[3], half[3];
+    double dt;
+    // cell grid (global grid; a slab rank stores cell layers [cx0, cx0 + ncxLocal) incl. ghost layers)
+    int32_t nc[3];                // global cell counts (split_cells, cuCellList.cu:9-34)
+    int32_t ncxLocal, cx0;        // local x-layers and global index of local layer 0 (may be negative: periodic ghost)
+    int32_t nCellLocal;
+    int32_t hw[3];                // stencil half-widths: ceil(rMax / cell edge)
+    int32_t nOff[3];              // offsets visited per axis = min(2 hw + 1, nc)
+    double csz[3], icsz[3];
+    double r2Max;
+    // electrostatics (cuStruct.h:388-391 ; elec.cpp:399-405)
+    int32_t elec_type, use_radii;
+    double alpha, el_scale, el_scale2, daipi2, rReal, fcoul, sqrtpi;
+    double E[3];                  // external field gradient
+    // thermostat
+    int32_t tstat, nEq, freqEq, pad0;
+    double tKin, revDegFree, rkB;
+    double revLight, radFrac, radThr, numPi;
+    uint64_t seed;
+    int32_t nAtGlobal, pad1;
+    // slab decomposition
+    double xlo, xhi;              // owned x-range [xlo, xhi)
+    int32_t rank, nranks;
+};
+
+// reduction slots of the per-block partial buffer (deterministic two-stage sums)
+enum PartialSlot
+{
+    PS_EFIELD = 0, PS_MOM_XN, PS_MOM_XP, PS_MOM_YN, PS_MOM_YP, PS_MOM_ZN, PS_MOM_ZP,
+    PS_CNT_XN, PS_CNT_XP, PS_CNT_YN, PS_CNT_YP, PS_CNT_ZN, PS_CNT_ZP,
+    PS_EVDW, PS_ECOUL, PS_DROPPED, PS_EKIN, PS_ETEMP, PS_COUNT
+};
+
+// device-resident scalars (the energy / momentum block of cudaMD, cuStruct.h:230-247)
+struct DevStats
+{
+    long long step;
+    double engKin, engVdW, engCoul, engElecField, engTemp, engTot, engPot, temperature;
+    double mom[6];                // Xn, Xp, Yn, Yp, Zn, Zp accumulated over the run (box.cpp:230-295)
+    long long cross[6];
+    long long dropped;
+    double vscale;                // equilibration velocity scale decided for the current step (1 = none)
+    double local[PS_COUNT];       // this rank's per-step sums before the cross-rank reduction
+};
+
+}  // namespace aztot

@@ -1,0 +1,108 @@
+// Step driver + device management of one rank: the MI355X-native counterpart of the reference's
+// init_cudaMD / md_to_host / free_device_md (cuInit.cu:756-1374) and of the loop body of
+// main.cu:281-410.  One HIP stream, no host synchronisation inside a step (the reference blocks on
+// cudaThreadSynchronize 11 times per step, main.cu:290-383), optional hipGraph replay.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "device_md.h"
+#include "model.h"
+#include "msg_layout.h"
+
+namespace aztot {
+
+struct Counts;
+
+struct KernelTimer
+{
+    std::string name;
+    double ms = 0.0;
+    long long calls = 0;
+};
+
+class Exchanger;   // slab halo / migration transport (RCCL or host-staged callback)
+
+class Engine
+{
+public:
+    Engine(const Model& model, const aztot_options& opt, int rank, int nranks, Exchanger* xch);
+    ~Engine();
+    Engine(const Engine&) = delete;
+
+    void step(int nsteps);
+    void forces();                          // sort + pair forces on the current positions
+    void get_stats(aztot_stats& out);
+    void md_to_host(aztot_state& out);
+    void set_state(const aztot_state& in);
+    int kernel_times(std::vector<KernelTimer>& out);
+    void reset_kernel_times();
+    int n_atoms_global() const { return model_.nAt; }
+
+private:
+    void choose_cells();
+    void allocate();
+    void upload_initial();
+    void sort_and_forces(bool integrate_first);
+    void launch_step_kernels();
+    void launch_pair();
+    void exchange_halo();
+    void collect_and_finalize(unsigned slotMask, bool advance);
+    void check_overflow();
+    void sync();
+    template <typename F> void timed(const char* name, F&& launch);
+    AtomArrays& cur() { return buf_[cur_]; }
+    AtomArrays& oth() { return buf_[cur_ ^ 1]; }
+
+    Model model_;
+    aztot_options opt_;
+    StepParams P_{};
+    SpecTable S_{};
+    int rank_, nranks_;
+    Exchanger* xch_;
+
+    hipStream_t stream_ = nullptr;
+    int capacity_ = 0;          // atoms that fit in the per-atom arrays (owned + ghosts + slack)
+    int nCellAlloc_ = 0;
+    int maxBlocks_ = 0;
+    AtomArrays buf_[2]{};
+    int cur_ = 0;
+    std::vector<void*> allocs_;
+    DevPot* dPots_ = nullptr;
+    int32_t *dCellOf_ = nullptr, *dSlotOf_ = nullptr, *dCellCount_ = nullptr, *dCellStart_ = nullptr;
+    int32_t *dTmpId_ = nullptr, *dTmpSrc_ = nullptr, *dTmpCell_ = nullptr, *dCellOfSorted_ = nullptr;
+    double* dPartials_ = nullptr;
+    DevStats* dStats_ = nullptr;
+    Counts* dCounts_ = nullptr;
+    double *dPhotons_ = nullptr, *dUvx_ = nullptr, *dUvy_ = nullptr, *dUvz_ = nullptr;
+    double* dEkGlobal_ = nullptr;   // kinetic energy over all ranks (equilibration scaling only)
+    char* dMsg_[4] = {nullptr, nullptr, nullptr, nullptr};   // sendLeft, sendRight, fromLeft, fromRight
+    MsgLayout lay_{};
+    int pairBlocks_ = 0, pairBlocksUsed_ = 0;
+
+    // statistics window for the wall-momentum pressure (main.cpp:143-163)
+    double lastMom_[6] = {0, 0, 0, 0, 0, 0};
+    double pressure_ = 0.0;
+    long long lastPresStep_ = 0;
+
+    // profiling
+    bool profile_ = false;
+    std::vector<KernelTimer> timers_;
+    std::map<std::string, int> timerIndex_;
+    struct PendingEvent { int idx; hipEvent_t a, b; };
+    std::vector<PendingEvent> pending_;
+    std::vector<hipEvent_t> eventPool_;
+    void drain_events();
+
+    // hipGraph replay of a pair of steps (ping-pong buffers)
+    hipGraph_t graph_[2] = {nullptr, nullptr};
+    hipGraphExec_t graphExec_[2] = {nullptr, nullptr};
+    bool capturing_ = false;
+};
+
+void check_hip(hipError_t e, const char* what);
+
+}  // namespace aztot

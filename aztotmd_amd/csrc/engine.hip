@@ -1,0 +1,538 @@
+// Engine: device management + step driver (see engine.h).
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+#include "exchange.h"
+#include "kernels.hip.h"
+#include "pair_tile.hip.h"
+#include "slab.hip.h"
+
+namespace aztot {
+
+void check_hip(hipError_t e, const char* what)
+{
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+#define HIP_CHECK(x) check_hip((x), #x)
+
+namespace {
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+}  // namespace
+
+template <typename F>
+void Engine::timed(const char* name, F&& launch)
+{
+    if (!profile_ || capturing_) { launch(); return; }
+    int idx;
+    auto it = timerIndex_.find(name);
+    if (it == timerIndex_.end())
+    {
+        idx = (int)timers_.size();
+        timers_.push_back(KernelTimer{name, 0.0, 0});
+        timerIndex_[name] = idx;
+    }
+    else idx = it->second;
+    auto get = [&]() {
+        if (!eventPool_.empty()) { hipEvent_t e = eventPool_.back(); eventPool_.pop_back(); return e; }
+        hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
+    };
+    hipEvent_t a = get(), b = get();
+    HIP_CHECK(hipEventRecord(a, stream_));
+    launch();
+    HIP_CHECK(hipEventRecord(b, stream_));
+    pending_.push_back({idx, a, b});
+    if (pending_.size() > 8192) { HIP_CHECK(hipStreamSynchronize(stream_)); drain_events(); }
+}
+
+void Engine::drain_events()
+{
+    for (auto& p : pending_)
+    {
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+        timers_[p.idx].ms += ms;
+        timers_[p.idx].calls += 1;
+        eventPool_.push_back(p.a); eventPool_.push_back(p.b);
+    }
+    pending_.clear();
+}
+
+void Engine::sync()
+{
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    if (profile_) drain_events();
+}
+
+int Engine::kernel_times(std::vector<KernelTimer>& out) { sync(); out = timers_; return (int)out.size(); }
+void Engine::reset_kernel_times() { sync(); for (auto& t : timers_) { t.ms = 0; t.calls = 0; } }
+
+// ---------------------------------------------------------------------------------------------------
+// cell grid: split_cells (cuCellList.cu:9-34, div_type 1: edge >= requested size).  No pair tables are
+// built (the reference's are O(nCell^2), cuCellList.cu:516-531): the stencil is walked on the fly with
+// half-width ceil(rMax / edge) per axis (cells may be smaller than the cut-off).
+// ---------------------------------------------------------------------------------------------------
+void Engine::choose_cells()
+{
+    const Model& m = model_;
+    double size = opt_.cell_size > 0 ? opt_.cell_size : ((m.use_clist && m.desired_cell_size > 0) ? m.desired_cell_size : m.rMax);
+    if (!(size > 0)) size = std::max(m.L[0], std::max(m.L[1], m.L[2]));
+    for (int k = 0; k < 3; k++)
+    {
+        int n = (int)std::floor(m.L[k] / size);
+        if (n < 1) n = 1;
+        if (n > 1024) n = 1024;
+        P_.nc[k] = n;
+        P_.csz[k] = m.L[k] / n;
+        P_.icsz[k] = n / m.L[k];
+        int hw = (m.rMax > 0) ? (int)std::ceil(m.rMax / P_.csz[k] - 1e-12) : 0;
+        if (hw < 0) hw = 0;
+        P_.hw[k] = hw;
+        P_.nOff[k] = std::min(2 * hw + 1, n);
+    }
+    if (nranks_ > 1)
+    {
+        // slab decomposition along x: contiguous, balanced runs of cell layers
+        const int n = P_.nc[0], hw = std::max(P_.hw[0], 1);
+        P_.hw[0] = hw;
+        const int lo = (int)((long long)n * rank_ / nranks_), hi = (int)((long long)n * (rank_ + 1) / nranks_);
+        if (hi - lo < 2 * hw)
+            throw std::runtime_error("slab decomposition: every rank needs at least 2*ceil(rc/cell) cell layers along x");
+        if ((hi - lo) + 2 * hw > n)
+            throw std::runtime_error("slab decomposition: ghost layers would overlap the rank's own layers (box too small for this rank count)");
+        P_.cx0 = lo - hw;
+        P_.ncxLocal = (hi - lo) + 2 * hw;
+        P_.xlo = lo * P_.csz[0];
+        P_.xhi = hi * P_.csz[0];
+        P_.nOff[0] = 2 * hw + 1;
+    }
+    else
+    {
+        P_.cx0 = 0; P_.ncxLocal = P_.nc[0]; P_.xlo = 0.0; P_.xhi = m.L[0];
+    }
+    P_.nCellLocal = P_.ncxLocal * P_.nc[1] * P_.nc[2];
+}
+
+Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nranks, Exchanger* xch)
+    : model_(model), opt_(opt), rank_(rank), nranks_(nranks), xch_(xch)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        throw std::runtime_error("no HIP device available: the azTotMD hot path has no CPU fallback");
+    if (opt_.device < 0 || opt_.device >= ndev) throw std::runtime_error("HIP device ordinal out of range");
+    HIP_CHECK(hipSetDevice(opt_.device));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    profile_ = opt_.profile != 0;
+    if (nranks_ > 1 && !xch_) throw std::runtime_error("slab decomposition needs an exchanger");
+
+    const Model& m = model_;
+    P_.nSpec = m.nSpec();
+    P_.nAtGlobal = m.nAt;
+    for (int k = 0; k < 3; k++) { P_.L[k] = m.L[k]; P_.invL[k] = 1.0 / m.L[k]; P_.half[k] = m.L[k] * 0.5; P_.E[k] = m.E[k]; }
+    P_.dt = m.tSt;
+    P_.r2Max = m.r2Max;
+    P_.elec_type = m.elec_type; P_.alpha = m.alpha; P_.el_scale = m.el_scale; P_.el_scale2 = m.el_scale2; P_.daipi2 = m.daipi2;
+    P_.rReal = m.rReal; P_.fcoul = units::Fcoul_scale; P_.sqrtpi = std::sqrt(units::pi);
+    P_.tstat = m.tstat_type; P_.nEq = m.nEq; P_.freqEq = m.freqEq; P_.tKin = m.tKin; P_.revDegFree = m.revDegFree; P_.rkB = 1.0 / units::kB;
+    P_.revLight = 3.33567e-5;   // cuTemp.cu:225 (SURVEY C-19: 100x the physical 1/c, kept for behavioural parity)
+    P_.radFrac = 0.9;           // cuTemp.cu:639
+    P_.radThr = 1e-4;           // cuTemp.cu:747
+    P_.numPi = 3.14159;         // cuTemp.cu:228
+    P_.seed = opt_.seed;
+    P_.rank = rank_; P_.nranks = nranks_;
+    P_.use_radii = 0;
+    for (const auto& p : m.pairpots) if (p.type && p.use_radii) P_.use_radii = 1;
+    P_.single_lj = (m.nSpec() == 1 && m.pairpots[0].type == AZTOT_VDW_LJ && m.elec_type == AZTOT_ELEC_NONE) ? 1 : 0;
+    std::memset(&S_, 0, sizeof(S_));
+    for (int i = 0; i < m.nSpec(); i++)
+    {
+        const Species& s = m.species[i];
+        S_.mass[i] = s.mass; S_.charge[i] = s.charge; S_.rMhdt[i] = s.rMass_hdt;
+        S_.radA[i] = s.radA; S_.radB[i] = s.radB; S_.mxEng[i] = s.mxEng;
+        S_.charged[i] = s.charged; S_.frozen[i] = s.frozen;
+    }
+    choose_cells();
+    allocate();
+    upload_initial();
+}
+
+Engine::~Engine()
+{
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (int g = 0; g < 2; g++)
+    {
+        if (graphExec_[g]) (void)hipGraphExecDestroy(graphExec_[g]);
+        if (graph_[g]) (void)hipGraphDestroy(graph_[g]);
+    }
+    for (auto& p : pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : eventPool_) (void)hipEventDestroy(e);
+    for (void* p : allocs_) (void)hipFree(p);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::allocate()
+{
+    const int N = model_.nAt;
+    if (nranks_ > 1)
+    {
+        // owned share + two ghost slabs + migration slack, with head-room for density fluctuations
+        const double frac = (double)P_.ncxLocal / P_.nc[0];
+        capacity_ = (int)std::min<double>((double)N, std::ceil(N * frac * 1.5) + 4096);
+        const double layerAtoms = (double)N / P_.nc[0];
+        lay_.haloCap = (int)std::min<double>((double)N, std::ceil(layerAtoms * P_.hw[0] * 1.6) + 1024);
+        lay_.migCap = (int)std::min<double>((double)N, std::ceil(layerAtoms * 0.25) + 1024);
+    }
+    else capacity_ = N;
+    nCellAlloc_ = P_.nCellLocal;
+    pairBlocks_ = std::max(div_up(capacity_, kBlock), pair_tile_grid(P_));
+    maxBlocks_ = std::max(div_up(capacity_, kBlock), pairBlocks_) + 1;
+    auto alloc = [&](size_t bytes) { void* p = nullptr; HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16))); allocs_.push_back(p); return p; };
+    const size_t nd = sizeof(double) * (size_t)capacity_, ni = sizeof(int32_t) * (size_t)capacity_;
+    for (int b = 0; b < 2; b++)
+    {
+        AtomArrays& A = buf_[b];
+        double** d[] = {&A.x, &A.y, &A.z, &A.vx, &A.vy, &A.vz, &A.fx, &A.fy, &A.fz, &A.U, &A.rad};
+        for (auto pp : d) { *pp = (double*)alloc(nd); HIP_CHECK(hipMemsetAsync(*pp, 0, nd, stream_)); }
+        A.type = (int32_t*)alloc(ni); A.id = (int32_t*)alloc(ni);
+        HIP_CHECK(hipMemsetAsync(A.type, 0, ni, stream_)); HIP_CHECK(hipMemsetAsync(A.id, 0, ni, stream_));
+    }
+    dCellOf_ = (int32_t*)alloc(ni); dSlotOf_ = (int32_t*)alloc(ni);
+    dTmpId_ = (int32_t*)alloc(ni); dTmpSrc_ = (int32_t*)alloc(ni); dTmpCell_ = (int32_t*)alloc(ni); dCellOfSorted_ = (int32_t*)alloc(ni);
+    dCellCount_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)(nCellAlloc_ + 1));
+    dCellStart_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)(nCellAlloc_ + 1));
+    HIP_CHECK(hipMemsetAsync(dCellCount_, 0, sizeof(int32_t) * (size_t)(nCellAlloc_ + 1), stream_));
+    HIP_CHECK(hipMemsetAsync(dCellStart_, 0, sizeof(int32_t) * (size_t)(nCellAlloc_ + 1), stream_));
+    dPartials_ = (double*)alloc(sizeof(double) * (size_t)PS_COUNT * maxBlocks_);
+    HIP_CHECK(hipMemsetAsync(dPartials_, 0, sizeof(double) * (size_t)PS_COUNT * maxBlocks_, stream_));
+    dStats_ = (DevStats*)alloc(sizeof(DevStats));
+    {
+        DevStats zero;
+        std::memset(&zero, 0, sizeof(zero));
+        zero.vscale = 1.0;          // "no equilibration scaling"; only k_scale_decision ever changes it
+        HIP_CHECK(hipMemcpy(dStats_, &zero, sizeof(DevStats), hipMemcpyHostToDevice));
+    }
+    dCounts_ = (Counts*)alloc(sizeof(Counts));
+    dEkGlobal_ = (double*)alloc(sizeof(double) * 2);
+    if (nranks_ > 1)
+    {
+        for (int k = 0; k < 4; k++) { dMsg_[k] = (char*)alloc(lay_.bytes()); HIP_CHECK(hipMemsetAsync(dMsg_[k], 0, lay_.bytes(), stream_)); }
+    }
+    const int ns = model_.nSpec();
+    std::vector<DevPot> pots((size_t)ns * ns);
+    for (int a = 0; a < ns; a++)
+        for (int b = 0; b < ns; b++)
+        {
+            const PairPot& p = model_.pot(a, b);
+            DevPot& d = pots[(size_t)a * ns + b];
+            d.type = p.type; d.use_radii = p.use_radii; d.p0 = p.p0; d.p1 = p.p1; d.p2 = p.p2; d.p3 = p.p3; d.p4 = p.p4; d.r2cut = p.r2cut;
+        }
+    dPots_ = (DevPot*)alloc(sizeof(DevPot) * pots.size());
+    HIP_CHECK(hipMemcpyAsync(dPots_, pots.data(), sizeof(DevPot) * pots.size(), hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::upload_initial()
+{
+    const Model& m = model_;
+    const int N = m.nAt;
+    // which atoms start on this rank: all of them on one GPU, the slab's cell layers otherwise
+    std::vector<int32_t> ids; ids.reserve(capacity_);
+    for (int i = 0; i < N; i++)
+    {
+        if (nranks_ > 1)
+        {
+            int gx = (int)std::floor(m.x[i] * P_.icsz[0]);
+            gx %= P_.nc[0]; if (gx < 0) gx += P_.nc[0];
+            const int lo = P_.cx0 + P_.hw[0], hi = lo + P_.ncxLocal - 2 * P_.hw[0];
+            if (gx < lo || gx >= hi) continue;
+        }
+        ids.push_back(i);
+    }
+    const int n = (int)ids.size();
+    if (n > capacity_) throw std::runtime_error("slab capacity exceeded at initialisation");
+    AtomArrays& A = cur();
+    std::vector<double> tmp(std::max(n, 1));
+    auto up = [&](double* dst, const std::vector<double>& src) {
+        for (int k = 0; k < n; k++) tmp[k] = src[ids[k]];
+        HIP_CHECK(hipMemcpy(dst, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    };
+    up(A.x, m.x); up(A.y, m.y); up(A.z, m.z); up(A.vx, m.vx); up(A.vy, m.vy); up(A.vz, m.vz);
+    std::vector<int32_t> ty(std::max(n, 1));
+    for (int k = 0; k < n; k++) ty[k] = m.types[ids[k]];
+    HIP_CHECK(hipMemcpy(A.type, ty.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(A.id, ids.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    if (m.tstat_type == AZTOT_TSTAT_RADI)
+    {   // init_cuda_tstat: cuTemp.cu:25-60 ; tables: read_tstat temperature.cpp:113-245
+        std::vector<double> ph(N), ux(kNumUnitVectors), uy(kNumUnitVectors), uz(kNumUnitVectors);
+        photon_engs(N, ph.data(), m.Temp, opt_.seed);
+        unit_vectors(ux.data(), uy.data(), uz.data());
+        auto alloc_up = [&](double*& d, const std::vector<double>& h) {
+            void* p = nullptr; HIP_CHECK(hipMalloc(&p, sizeof(double) * h.size())); allocs_.push_back(p); d = (double*)p;
+            HIP_CHECK(hipMemcpy(d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+        };
+        alloc_up(dPhotons_, ph); alloc_up(dUvx_, ux); alloc_up(dUvy_, uy); alloc_up(dUvz_, uz);
+        for (int k = 0; k < n; k++) tmp[k] = initial_radius(opt_.seed, (uint64_t)ids[k]);
+        HIP_CHECK(hipMemcpy(A.rad, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    Counts c{};
+    c.ownedBegin = 0; c.ownedEnd = n; c.nTotal = n; c.srcBegin = 0; c.srcEnd = n;
+    HIP_CHECK(hipMemcpy(dCounts_, &c, sizeof(Counts), hipMemcpyHostToDevice));
+    if (opt_.initial_forces) forces();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pair kernel dispatch
+// ---------------------------------------------------------------------------------------------------
+void Engine::launch_pair()
+{
+    int variant = opt_.pair_variant;
+    if (variant == 0) variant = pair_tile_supported(P_) ? 2 : 1;
+    if (variant == 2 && !pair_tile_supported(P_)) variant = 1;
+    if (variant == 2)
+        timed("pair_tile", [&] { launch_pair_tile(P_, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_); });
+    else
+        timed("pair_atom", [&] {
+            hipLaunchKernelGGL(k_pair_atom, dim3(div_up(capacity_, kBlock)), dim3(kBlock), 0, stream_, P_, S_, dPots_, cur(), dCounts_, dCellStart_,
+                               dCellOfSorted_, dPartials_, maxBlocks_);
+        });
+    pairBlocksUsed_ = (variant == 2) ? pair_tile_grid(P_) : div_up(capacity_, kBlock);
+}
+
+// one message to each x-neighbour: migrants + halo (slab.hip.h)
+void Engine::exchange_halo()
+{
+    const int gridAtoms = div_up(capacity_, kBlock);
+    HIP_CHECK(hipMemsetAsync(dMsg_[0], 0, sizeof(SendHeader), stream_));
+    HIP_CHECK(hipMemsetAsync(dMsg_[1], 0, sizeof(SendHeader), stream_));
+    timed("pack_halo", [&] {
+        hipLaunchKernelGGL(k_pack, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, cur(), dCounts_, dCellOf_, lay_, dMsg_[0], dMsg_[1]);
+    });
+    const int left = (rank_ + nranks_ - 1) % nranks_, right = (rank_ + 1) % nranks_;
+    timed("exchange", [&] { xch_->exchange(left, right, dMsg_[0], dMsg_[1], dMsg_[2], dMsg_[3], lay_.bytes(), stream_); });
+    const int recvCap = 2 * (lay_.migCap + lay_.haloCap);
+    timed("unpack_halo", [&] {
+        hipLaunchKernelGGL(k_unpack, dim3(div_up(recvCap, kBlock)), dim3(kBlock), 0, stream_, P_, cur(), dCounts_, capacity_, lay_, dMsg_[2], dMsg_[3],
+                           dCellOf_, dSlotOf_, dCellCount_);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------
+// iter_fastCellList (cuPairs.cu:2519-2567): histogram -> [halo] -> scan -> sort -> pair forces
+// ---------------------------------------------------------------------------------------------------
+void Engine::sort_and_forces(bool integrate_first)
+{
+    const int gridAtoms = div_up(capacity_, kBlock);
+    if (integrate_first)
+        timed("integrate1_bin", [&] {
+            hipLaunchKernelGGL(k_integrate1_bin<true>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
+                               dCellCount_, dPartials_, maxBlocks_);
+        });
+    else
+    {
+        HIP_CHECK(hipMemsetAsync(dCellCount_, 0, sizeof(int32_t) * (size_t)(nCellAlloc_ + 1), stream_));
+        timed("bin", [&] {
+            hipLaunchKernelGGL(k_integrate1_bin<false>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
+                               dCellCount_, dPartials_, maxBlocks_);
+        });
+    }
+    if (nranks_ > 1) exchange_halo();
+    timed("scan_cells", [&] {
+        hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, stream_, P_.nCellLocal, dCellCount_, dCellStart_, P_, dCounts_, nranks_ > 1 ? 1 : 0);
+    });
+    timed("place", [&] {
+        hipLaunchKernelGGL(k_place, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellOf_, dSlotOf_, dCellStart_, cur().id, dTmpId_, dTmpSrc_,
+                           dTmpCell_);
+    });
+    timed("rank_gather", [&] {
+        hipLaunchKernelGGL(k_rank_gather, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellStart_, dTmpId_, dTmpSrc_, dTmpCell_, cur(), oth(),
+                           dCellOfSorted_, 0);
+    });
+    cur_ ^= 1;
+    launch_pair();
+}
+
+void Engine::collect_and_finalize(unsigned slotMask, bool advance)
+{
+    timed("collect", [&] {
+        hipLaunchKernelGGL(k_collect, dim3(1), dim3(1024), 0, stream_, dPartials_, maxBlocks_, div_up(capacity_, kBlock), pairBlocksUsed_, dStats_, slotMask);
+    });
+    timed("finalize", [&] { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, stream_, P_, dStats_, advance ? 1 : 0); });
+}
+
+void Engine::forces()
+{
+    sort_and_forces(false);
+    // energies of this configuration; kinetic energy and wall counters are left untouched
+    const unsigned mask = (1u << PS_EVDW) | (1u << PS_ECOUL) | (1u << PS_DROPPED);
+    collect_and_finalize(mask, false);
+    HIP_CHECK(hipMemsetAsync(dCellCount_, 0, sizeof(int32_t) * (size_t)(nCellAlloc_ + 1), stream_));
+    sync();
+    check_overflow();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one iteration of the loop body of main.cu:281-410 (serial twin: main.cpp:89-142)
+// ---------------------------------------------------------------------------------------------------
+void Engine::launch_step_kernels()
+{
+    const int gridAtoms = div_up(capacity_, kBlock);
+    sort_and_forces(true);
+    timed("integrate2", [&] {
+        hipLaunchKernelGGL(k_integrate2, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal, dPartials_,
+                           maxBlocks_);
+    });
+    unsigned mask = (1u << PS_COUNT) - 1u;
+    const bool equil = P_.nEq > 0;
+    if (equil)
+    {
+        timed("reduce_kin", [&] {
+            hipLaunchKernelGGL(k_reduce_kin, dim3(1), dim3(1024), 0, stream_, P_, dPartials_, maxBlocks_, gridAtoms, dStats_, dEkGlobal_);
+        });
+        if (nranks_ > 1)
+        {   // the scaling factor needs the kinetic energy of ALL ranks (equilibration steps only)
+            double ek = 0.0;
+            HIP_CHECK(hipMemcpyAsync(&ek, dEkGlobal_, sizeof(double), hipMemcpyDeviceToHost, stream_));
+            HIP_CHECK(hipStreamSynchronize(stream_));
+            xch_->allreduce_sum(&ek, 1, stream_);
+            HIP_CHECK(hipMemcpyAsync(dEkGlobal_, &ek, sizeof(double), hipMemcpyHostToDevice, stream_));
+        }
+        timed("scale_decision", [&] { hipLaunchKernelGGL(k_scale_decision, dim3(1), dim3(64), 0, stream_, P_, dStats_, dEkGlobal_); });
+        mask &= ~(1u << PS_EKIN);
+    }
+    if (equil || P_.tstat == AZTOT_TSTAT_RADI)
+        timed("post_tstat", [&] {
+            hipLaunchKernelGGL(k_post, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dStats_, dPhotons_, dUvx_, dUvy_, dUvz_,
+                               dPartials_, maxBlocks_);
+        });
+    else
+        mask &= ~(1u << PS_ETEMP);
+    collect_and_finalize(mask, true);
+}
+
+void Engine::step(int nsteps)
+{
+    if (nsteps <= 0) return;
+    int done = 0;
+    const bool can_graph = opt_.use_graph && nranks_ == 1 && !profile_;
+    if (can_graph && nsteps >= 2)
+    {
+        // a graph holds TWO consecutive steps (the sort ping-pongs between the two per-atom buffers), and there is
+        // one graph per starting buffer because kernel arguments are baked in at capture time
+        const int g = cur_;
+        if (!graphExec_[g])
+        {
+            capturing_ = true;
+            HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+            launch_step_kernels();
+            launch_step_kernels();
+            HIP_CHECK(hipStreamEndCapture(stream_, &graph_[g]));
+            capturing_ = false;
+            HIP_CHECK(hipGraphInstantiate(&graphExec_[g], graph_[g], nullptr, nullptr, 0));
+            // the capture itself executed nothing and left cur_ where it was
+        }
+        while (nsteps - done >= 2) { HIP_CHECK(hipGraphLaunch(graphExec_[g], stream_)); done += 2; }
+    }
+    for (; done < nsteps; done++) launch_step_kernels();
+    sync();
+    check_overflow();
+}
+
+void Engine::check_overflow()
+{
+    if (nranks_ <= 1) return;
+    Counts c;
+    HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
+    if (c.overflow) throw std::runtime_error("slab decomposition: a fixed-capacity halo/migration/atom buffer overflowed");
+}
+
+void Engine::get_stats(aztot_stats& out)
+{
+    sync();
+    DevStats s;
+    HIP_CHECK(hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost));
+    double v[24];
+    v[0] = s.engKin; v[1] = s.engVdW; v[2] = s.engCoul; v[3] = s.engElecField; v[4] = s.engTemp;
+    for (int k = 0; k < 6; k++) { v[5 + k] = s.mom[k]; v[11 + k] = (double)s.cross[k]; }
+    v[17] = (double)s.dropped;
+    if (nranks_ > 1) xch_->allreduce_sum(v, 18, stream_);
+    std::memset(&out, 0, sizeof(out));
+    out.step = s.step;
+    out.time = s.step * model_.tSt;
+    out.engKin = v[0]; out.engVdW = v[1]; out.engCoul = v[2]; out.engElecField = v[3]; out.engTemp = v[4];
+    out.engPot = out.engCoul + out.engVdW;
+    out.engTot = out.engElecField + out.engVdW + out.engCoul + out.engKin;          // calc_chars integrators.cpp:72
+    out.temperature = 2.0 * out.engKin * model_.revDegFree * (1.0 / units::kB);     // integrators.cpp:67
+    out.negMom[0] = v[5]; out.posMom[0] = v[6]; out.negMom[1] = v[7]; out.posMom[1] = v[8]; out.negMom[2] = v[9]; out.posMom[2] = v[10];
+    out.negCross[0] = (int64_t)v[11]; out.posCross[0] = (int64_t)v[12]; out.negCross[1] = (int64_t)v[13];
+    out.posCross[1] = (int64_t)v[14]; out.negCross[2] = (int64_t)v[15]; out.posCross[2] = (int64_t)v[16];
+    out.pairs_dropped = (int64_t)v[17];
+    out.n_cells = (int64_t)P_.nc[0] * P_.nc[1] * P_.nc[2];
+    // pressure from the wall momentum over the window since the previous evaluation (main.cpp:143-163)
+    if (s.step - lastPresStep_ >= std::max(1, model_.stat))
+    {
+        const double dtw = (s.step - lastPresStep_) * model_.tSt;
+        const double revS[6] = {1.0 / (model_.L[1] * model_.L[2]), 1.0 / (model_.L[1] * model_.L[2]), 1.0 / (model_.L[0] * model_.L[2]),
+                                1.0 / (model_.L[0] * model_.L[2]), 1.0 / (model_.L[0] * model_.L[1]), 1.0 / (model_.L[0] * model_.L[1])};
+        double p = 0.0;
+        for (int k = 0; k < 6; k++) { p += 2.0 * units::pressure_factor * revS[k] * (v[5 + k] - lastMom_[k]) / dtw; lastMom_[k] = v[5 + k]; }
+        pressure_ = p / 6.0;
+        lastPresStep_ = s.step;
+    }
+    out.pressure = pressure_;
+}
+
+// md_to_host (cuInit.cu:1212-1262).  The reference returns the arrays in cell-sorted order (SURVEY C-20);
+// we put every atom back at its original index.  On several ranks each rank fills only the atoms it owns.
+void Engine::md_to_host(aztot_state& out)
+{
+    sync();
+    Counts c;
+    HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
+    const int n = c.ownedEnd - c.ownedBegin;
+    if (out.n_atoms < model_.nAt) throw std::runtime_error("md_to_host: output arrays too small");
+    std::vector<int32_t> ids(std::max(n, 1));
+    HIP_CHECK(hipMemcpy(ids.data(), cur().id + c.ownedBegin, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<double> tmp(std::max(n, 1));
+    auto down = [&](double* dst, const double* src) {
+        if (!dst) return;
+        HIP_CHECK(hipMemcpy(tmp.data(), src + c.ownedBegin, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+        for (int k = 0; k < n; k++) dst[ids[k]] = tmp[k];
+    };
+    AtomArrays& A = cur();
+    down(out.x, A.x); down(out.y, A.y); down(out.z, A.z); down(out.vx, A.vx); down(out.vy, A.vy); down(out.vz, A.vz);
+    down(out.fx, A.fx); down(out.fy, A.fy); down(out.fz, A.fz); down(out.U, A.U); down(out.radius, A.rad);
+    if (out.types)
+    {
+        std::vector<int32_t> ty(std::max(n, 1));
+        HIP_CHECK(hipMemcpy(ty.data(), A.type + c.ownedBegin, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+        for (int k = 0; k < n; k++) out.types[ids[k]] = ty[k];
+    }
+    out.n_atoms = n;   // number of atoms this rank wrote
+}
+
+// overwrite per-atom state (indexed by ORIGINAL atom id); used for exact restarts and stage-wise tests
+void Engine::set_state(const aztot_state& in)
+{
+    sync();
+    Counts c;
+    HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
+    const int n = c.ownedEnd - c.ownedBegin;
+    std::vector<int32_t> ids(std::max(n, 1));
+    HIP_CHECK(hipMemcpy(ids.data(), cur().id + c.ownedBegin, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<double> tmp(std::max(n, 1));
+    auto up = [&](const double* src, double* dst) {
+        if (!src) return;
+        for (int k = 0; k < n; k++) tmp[k] = src[ids[k]];
+        HIP_CHECK(hipMemcpy(dst + c.ownedBegin, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    };
+    AtomArrays& A = cur();
+    up(in.x, A.x); up(in.y, A.y); up(in.z, A.z); up(in.vx, A.vx); up(in.vy, A.vy); up(in.vz, A.vz);
+    up(in.fx, A.fx); up(in.fy, A.fy); up(in.fz, A.fz); up(in.U, A.U); up(in.radius, A.rad);
+}
+
+}  // namespace aztot

@@ -1,0 +1,134 @@
+#include "exchange.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+namespace aztot {
+
+void check_hip(hipError_t e, const char* what);
+#define HIP_CHECK(x) check_hip((x), #x)
+
+// ---------------------------------------------------------------------------------------------------
+// host-staged transport (tests over gloo): D2H, caller's sendrecv, H2D.  The header at the front of each
+// message tells how many bytes are really in use, so only those travel.
+// ---------------------------------------------------------------------------------------------------
+void CallbackExchanger::exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight,
+                                 size_t bytes, hipStream_t stream)
+{
+    for (int k = 0; k < 2; k++) { hs_[k].resize(bytes); hr_[k].resize(bytes); }
+    HIP_CHECK(hipMemcpyAsync(hs_[0].data(), dSendLeft, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(hs_[1].data(), dSendRight, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    int64_t got = 0;
+    // leftward messages first (everyone sends left / receives from the right), then rightward ones
+    if (sr_(ctx_, left, hs_[0].data(), (int64_t)bytes, right, hr_[1].data(), (int64_t)bytes, &got) != 0)
+        throw std::runtime_error("slab exchange callback failed (leftward)");
+    if (sr_(ctx_, right, hs_[1].data(), (int64_t)bytes, left, hr_[0].data(), (int64_t)bytes, &got) != 0)
+        throw std::runtime_error("slab exchange callback failed (rightward)");
+    HIP_CHECK(hipMemcpyAsync(dFromLeft, hr_[0].data(), bytes, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(dFromRight, hr_[1].data(), bytes, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void CallbackExchanger::allreduce_sum(double* host, int n, hipStream_t)
+{
+    if (ar_(ctx_, host, n) != 0) throw std::runtime_error("slab allreduce callback failed");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RCCL transport
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi
+{
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi& rccl()
+{
+    static RcclApi api;
+    if (api.lib) return api;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.lib) break; }
+    if (!api.lib) throw std::runtime_error(std::string("cannot load RCCL: ") + dlerror());
+    auto sym = [&](const char* s) { void* p = dlsym(api.lib, s); if (!p) throw std::runtime_error(std::string("RCCL symbol missing: ") + s); return p; };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    return api;
+}
+
+void check_nccl(ncclResult_t r, const char* what)
+{
+    if (r != ncclSuccess) throw std::runtime_error(std::string("RCCL error in ") + what + ": " + rccl().GetErrorString(r));
+}
+}  // namespace
+
+int RcclExchanger::id_bytes() { return (int)sizeof(ncclUniqueId); }
+void RcclExchanger::make_id(void* out)
+{
+    ncclUniqueId id;
+    check_nccl(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    std::memcpy(out, &id, sizeof(id));
+}
+
+RcclExchanger::RcclExchanger(int rank, int nranks, const void* id_bytes)
+{
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof(id));
+    ncclComm_t c;
+    check_nccl(rccl().CommInitRank(&c, nranks, id, rank), "ncclCommInitRank");
+    comm_ = c;
+    HIP_CHECK(hipMalloc((void**)&dScratch_, sizeof(double) * 256));
+}
+
+RcclExchanger::~RcclExchanger()
+{
+    if (dScratch_) (void)hipFree(dScratch_);
+    if (comm_) rccl().CommDestroy((ncclComm_t)comm_);
+}
+
+void RcclExchanger::exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight,
+                             size_t bytes, hipStream_t stream)
+{
+    RcclApi& a = rccl();
+    ncclComm_t c = (ncclComm_t)comm_;
+    check_nccl(a.GroupStart(), "ncclGroupStart");
+    // with two ranks both neighbours are the same peer: sends and receives are matched in issue order,
+    // so post them in the same order on both sides (leftward message first)
+    check_nccl(a.Send(dSendLeft, bytes, ncclChar, left, c, stream), "ncclSend(left)");
+    check_nccl(a.Recv(dFromRight, bytes, ncclChar, right, c, stream), "ncclRecv(right)");
+    check_nccl(a.Send(dSendRight, bytes, ncclChar, right, c, stream), "ncclSend(right)");
+    check_nccl(a.Recv(dFromLeft, bytes, ncclChar, left, c, stream), "ncclRecv(left)");
+    check_nccl(a.GroupEnd(), "ncclGroupEnd");
+}
+
+void RcclExchanger::allreduce_sum(double* host, int n, hipStream_t stream)
+{
+    if (n > 256) throw std::runtime_error("allreduce_sum: too many values");
+    HIP_CHECK(hipMemcpyAsync(dScratch_, host, sizeof(double) * n, hipMemcpyHostToDevice, stream));
+    check_nccl(rccl().AllReduce(dScratch_, dScratch_, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)comm_, stream), "ncclAllReduce");
+    HIP_CHECK(hipMemcpyAsync(host, dScratch_, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+}  // namespace aztot

@@ -1,0 +1,63 @@
+// Transport of the slab decomposition: one fixed-size message to each x-neighbour per step.
+//  * RcclExchanger    - ncclSend/ncclRecv on the engine's stream (RCCL over xGMI; point-to-point with the
+//                       two ring neighbours only, so every transfer rides its own xGMI link).
+//  * CallbackExchanger- host-staged through a caller-supplied function (gloo in the tests); correctness only.
+// RCCL is loaded with dlopen at first use, so the library itself has no link-time dependency on it.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/aztot.h"
+
+namespace aztot {
+
+class Exchanger
+{
+public:
+    virtual ~Exchanger() {}
+    // send `bytes` from dSendLeft to `left` and from dSendRight to `right`; receive the neighbours' messages
+    // (same size) into dFromLeft / dFromRight.  Ordered on `stream`.
+    virtual void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight,
+                          size_t bytes, hipStream_t stream) = 0;
+    // element-wise sum over ranks of n doubles held on the HOST (statistics; not on the per-step path)
+    virtual void allreduce_sum(double* host, int n, hipStream_t stream) = 0;
+    virtual bool device_side() const = 0;
+};
+
+class CallbackExchanger : public Exchanger
+{
+public:
+    CallbackExchanger(aztot_sendrecv_fn sr, aztot_allreduce_fn ar, void* ctx) : sr_(sr), ar_(ar), ctx_(ctx) {}
+    void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
+                  hipStream_t stream) override;
+    void allreduce_sum(double* host, int n, hipStream_t stream) override;
+    bool device_side() const override { return false; }
+
+private:
+    aztot_sendrecv_fn sr_;
+    aztot_allreduce_fn ar_;
+    void* ctx_;
+    std::vector<char> hs_[2], hr_[2];
+};
+
+class RcclExchanger : public Exchanger
+{
+public:
+    RcclExchanger(int rank, int nranks, const void* id_bytes);
+    ~RcclExchanger() override;
+    void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
+                  hipStream_t stream) override;
+    void allreduce_sum(double* host, int n, hipStream_t stream) override;
+    bool device_side() const override { return true; }
+    static int id_bytes();
+    static void make_id(void* out);
+
+private:
+    void* comm_ = nullptr;
+    double* dScratch_ = nullptr;
+};
+
+}  // namespace aztot

@@ -1,0 +1,610 @@
+// Hand-written HIP kernels (gfx950 / CDNA4, wave64) of the azTotMD per-step hot path, fp64.
+//
+//  reference kernel (file:line)                          ours
+//  ---------------------------------------------------   ----------------------------------------------
+//  clear_clist            cuMDfunc.cu:693                folded into k_integrate2 (zeroes the histogram)
+//  verlet_1stage+count_cell cuMDfunc.cu:333, cuSort.cu:114  k_integrate1_bin
+//  calc_firstAtomInCell   cuSort.cu:130 (1 thread)       k_scan_cells (one 1024-thread workgroup)
+//  sort_atoms+refresh_arrays cuSort.cu:145,74            k_place + k_rank_gather (deterministic order)
+//  cell_list5a + cell_list4b_noshared + pair_1           k_pair_atom / k_pair_tile (no atomics, no tables)
+//     cuPairs.cu:2266,1474,117
+//  verlet_2stage + zero_engKin cuMDfunc.cu:521, cuTemp.cu:165   k_integrate2
+//  temp_scale/after_tscale cuTemp.cu:77,109              k_reduce_kin (decides the factor) + k_post
+//  tstat_radi9            cuTemp.cu:689                  k_post
+//  reset_quantities + calc_quantities cuMDfunc.cu:270, main.cu:121   k_finalize
+//
+// No MFMA anywhere: there is no dense contraction on this path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_md.h"
+#include "rng.h"
+
+namespace aztot {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------------------------
+// reductions: wave shuffle -> LDS -> thread 0, fixed order (deterministic for a fixed launch shape)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;
+}
+
+// sum over the workgroup; result valid in thread 0. `scratch` holds blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* scratch)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) r += scratch[k];
+    return r;
+}
+
+__device__ __forceinline__ void put_partial(double* partials, int maxBlocks, int slot, double v)
+{
+    partials[(size_t)slot * maxBlocks + blockIdx.x] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometry helpers
+// ------------------------------------------------------------------------------------------------
+// put_periodic: serial formula (box.cpp:230-295) + the GPU path's x >= L -> 0 safety (cuMDfunc.cu:64-69)
+__device__ __forceinline__ int wrap_coord(double& x, double L, double invL)
+{
+    int crossed = 0;
+    if (x < 0) { x += ((int)(-x * invL) + 1) * L; crossed = -1; }
+    else if (x > L) { x -= ((int)(x * invL)) * L; crossed = 1; }
+    if (x >= L) x = 0.0;
+    return crossed;
+}
+
+__device__ __forceinline__ int cell_coord(double x, double icsz, int n)
+{   // count_cell: cuSort.cu:119 - floor(x * cRevSize) in double; made robust for coordinates outside [0, L)
+    int c = (int)floor(x * icsz);
+    c %= n;
+    if (c < 0) c += n;
+    return c;
+}
+
+__device__ __forceinline__ int local_cell(const StepParams& P, double x, double y, double z)
+{
+    int gx = cell_coord(x, P.icsz[0], P.nc[0]);
+    int cy = cell_coord(y, P.icsz[1], P.nc[1]);
+    int cz = cell_coord(z, P.icsz[2], P.nc[2]);
+    int lx = gx - P.cx0;                 // window of x-layers held by this rank (periodic unwrap)
+    if (lx >= P.nc[0]) lx -= P.nc[0];
+    if (lx < 0) lx += P.nc[0];
+    return (lx * P.nc[1] + cy) * P.nc[2] + cz;
+}
+
+__device__ __forceinline__ void min_image(double& d, double L, double half)
+{   // delta_periodic: box.cpp:180-207
+    if (d > half) d -= L;
+    else if (d < -half) d += L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair functions: f = -(1/r) dU/dr, energy added to eV / eC.  Operation order follows the serial
+// reference (vdw.cpp:16-157, elec.cpp:415-444); elin/einv/surk follow cuVdW.cu:162-257 in fp64.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double vdw_force(const DevPot& v, double r2, double& r, double radi, double radj, double& eng)
+{
+    switch (v.type)
+    {
+    case 1:
+    {   // fer_lj vdw.cpp:16-26
+        double r2i = 1.0 / r2;
+        double sr2 = v.p1 * r2i;
+        double sr6 = sr2 * sr2 * sr2;
+        eng += v.p0 * sr6 * (sr6 - 1.0);
+        return v.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
+    }
+    case 2:
+    {   // fer_buckingham vdw.cpp:60-70
+        double r2i = 1.0 / r2, r4i = r2i * r2i;
+        if (r == 0.0) r = sqrt(r2);
+        double ex = exp(-r / v.p1);
+        eng += v.p0 * ex - v.p2 * r4i * r2i;
+        return v.p0 * ex / r / v.p1 - 6.0 * v.p2 * r4i * r4i;
+    }
+    case 3:
+    {   // fer_746 vdw.cpp:144-157
+        double r2i = 1.0 / r2, r4i = r2i * r2i;
+        double ri = (r == 0.0) ? sqrt(r2i) : 1.0 / r;
+        eng += r4i * (v.p0 * r2i * ri - v.p1 - v.p2 * r2i);
+        return r4i * r2i * (7.0 * v.p0 * r2i * ri - 4.0 * v.p1 - 6.0 * v.p2 * r2i);
+    }
+    case 4:
+    {   // fer_bhm vdw.cpp:102-112
+        double r2i = 1.0 / r2, r4i = r2i * r2i;
+        if (r == 0.0) r = sqrt(r2);
+        double ex = exp(v.p1 * (v.p2 - r));
+        eng += v.p0 * ex - v.p3 * r4i * r2i - v.p4 * r4i * r4i;
+        return v.p0 * v.p1 * ex / r - 6.0 * v.p3 * r4i * r4i - 8.0 * v.p4 * r4i * r4i * r2i;
+    }
+    case 5:
+    {   // cu_fer_elin cuVdW.cu:162-171
+        if (r == 0.0) r = sqrt(r2);
+        double ex = exp(-r / v.p1);
+        eng += v.p0 * ex + v.p2 * r;
+        return v.p0 * ex / r / v.p1 - v.p2 / r;
+    }
+    case 6:
+    {   // cu_fer_einv cuVdW.cu:200-208
+        if (r == 0.0) r = sqrt(r2);
+        double ex = exp(-r / v.p1);
+        eng += v.p0 * ex - v.p2 / r;
+        return v.p0 * ex / r / v.p1 - v.p2 / r / r2;
+    }
+    case 7:
+    {   // surk_pot cuVdW.cu:236-257
+        double c2ir_sum = v.p1 / (v.p2 * radi + v.p3 * radj);
+        double r_prod = radi * radj;
+        double C1ab2 = r_prod * r_prod * v.p0;
+        double r6 = r2 * r2 * r2;
+        double rr = sqrt(r2);
+        double ir6 = 1.0 / r6, ir = 1.0 / rr;
+        eng += r_prod * ir6 * (C1ab2 * ir - c2ir_sum);
+        return r_prod * ir6 / r2 * (7.0 * C1ab2 * ir - 6.0 * c2ir_sum);
+    }
+    }
+    return 0.0;
+}
+
+__device__ __forceinline__ double coul_force(const StepParams& P, double qq, double r2, double& eng)
+{   // r is passed by value in the serial reference (elec.h:16), so the VdW part never sees it
+    double kqq = qq * P.fcoul;
+    double r = sqrt(r2);
+    if (P.elec_type == 1)
+    {   // direct_coul elec.cpp:415-428
+        eng += kqq / r;
+        return kqq / r / r2;
+    }
+    else if (P.elec_type == 3)
+    {   // fennel elec.cpp:430-444
+        double ir = 1.0 / r;
+        double ar = P.alpha * r;
+        double erfcar = erfc(ar);
+        eng += kqq * (erfcar * ir - P.el_scale + P.el_scale2 * (r - P.rReal));
+        return kqq * ir * ((erfcar / r2 + P.daipi2 * exp(-ar * ar) * ir) - P.el_scale2);
+    }
+    else
+    {   // coul_iter elec.cpp:344-369 (real-space Ewald term)
+        double ar = P.alpha * r, erfcar = erfc(ar);
+        eng += kqq * erfcar / r;
+        return kqq / r / r2 * (erfcar + 2 * ar / P.sqrtpi * exp(-ar * ar));
+    }
+}
+
+// one candidate pair, seen from atom i (pair_inter integrators.cpp:139-185).  Every unordered pair is
+// visited from both ends, so each visit books half of the pair energy.
+struct PairAcc { double fx, fy, fz, eV, eC, dropped; };
+
+__device__ __forceinline__ void pair_visit(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots,
+                                           double dx, double dy, double dz, double r2, int ti, int tj, double radi, double radj,
+                                           PairAcc& a)
+{
+    double r = 0.0, f = 0.0, eV = 0.0, eC = 0.0;
+    if (P.elec_type != 0 && S.charged[ti] && S.charged[tj]) f += coul_force(P, S.charge[ti] * S.charge[tj], r2, eC);
+    const DevPot v = pots[ti * P.nSpec + tj];
+    if (v.type != 0 && r2 <= v.r2cut) f += vdw_force(v, r2, r, radi, radj, eV);
+    a.eV += 0.5 * eV; a.eC += 0.5 * eC;
+    if (f * f > 1e10) { a.dropped += 0.5; return; }          // integrators.cpp:170-174: energy booked, force dropped
+    a.fx += f * dx; a.fy += f * dy; a.fz += f * dz;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: first half-kick + drift + wrap + wall counters + cell histogram
+//     (verlet_1stage cuMDfunc.cu:333-519 ; serial integrate1_clst integrators.cpp:331-376)
+// ------------------------------------------------------------------------------------------------
+// index bookkeeping that lives on the device so that no step needs a host round trip
+struct Counts
+{
+    int32_t ownedBegin, ownedEnd;   // range of the sorted arrays this rank integrates
+    int32_t nTotal;                 // resident atoms (owned + ghosts) after the last sort
+    int32_t srcBegin, srcEnd;       // pre-sort source range: old owned range + atoms appended by k_unpack
+    int32_t nRecv;                  // atoms appended by k_unpack in the step in flight
+    int32_t overflow;               // sticky: a fixed-capacity buffer was too small
+    int32_t pad;
+};
+
+template <bool INTEGRATE>
+__global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTable S, AtomArrays A, const Counts* __restrict__ cnt,
+                                                           int32_t* __restrict__ cellOf, int32_t* __restrict__ slotOf,
+                                                           int32_t* __restrict__ cellCount, double* __restrict__ partials, int maxBlocks)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int begin = cnt->ownedBegin, end = cnt->ownedEnd;
+    const int i = begin + blockIdx.x * kBlock + threadIdx.x;
+    double eField = 0.0, mom[6] = {0, 0, 0, 0, 0, 0}, cross[6] = {0, 0, 0, 0, 0, 0};
+    int anyCross = 0;
+    if (i < end)
+    {
+        const int t = A.type[i];
+        double x = A.x[i], y = A.y[i], z = A.z[i];
+        if (INTEGRATE)
+        {
+            const double rM = S.rMhdt[t], m = S.mass[t];
+            double vx = A.vx[i] + rM * A.fx[i];
+            double vy = A.vy[i] + rM * A.fy[i];
+            double vz = A.vz[i] + rM * A.fz[i];
+            if (!S.frozen[t]) { x += vx * P.dt; y += vy * P.dt; z += vz * P.dt; }
+            int c;
+            c = wrap_coord(x, P.L[0], P.invL[0]);
+            if (c < 0) { mom[0] = m * (-vx); cross[0] = 1; anyCross = 1; } else if (c > 0) { mom[1] = m * vx; cross[1] = 1; anyCross = 1; }
+            c = wrap_coord(y, P.L[1], P.invL[1]);
+            if (c < 0) { mom[2] = m * (-vy); cross[2] = 1; anyCross = 1; } else if (c > 0) { mom[3] = m * vy; cross[3] = 1; anyCross = 1; }
+            c = wrap_coord(z, P.L[2], P.invL[2]);
+            if (c < 0) { mom[4] = m * (-vz); cross[4] = 1; anyCross = 1; } else if (c > 0) { mom[5] = m * vz; cross[5] = 1; anyCross = 1; }
+            A.vx[i] = vx; A.vy[i] = vy; A.vz[i] = vz;
+            A.x[i] = x; A.y[i] = y; A.z[i] = z;
+            eField = S.charge[t] * (x * P.E[0] + y * P.E[1] + z * P.E[2]);      // integrators.cpp:374 / cuMDfunc.cu:476
+        }
+        const int c = local_cell(P, x, y, z);
+        cellOf[i] = c;
+        slotOf[i] = atomicAdd(&cellCount[c], 1);
+    }
+    if (INTEGRATE)
+    {
+        double s = block_sum(eField, scratch);
+        if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EFIELD, s);
+        const int blockCross = __syncthreads_or(anyCross);     // wall crossings are rare: skip 12 reductions otherwise
+        for (int k = 0; k < 6; k++)
+        {
+            double a = 0.0, b = 0.0;
+            if (blockCross) { a = block_sum(mom[k], scratch); b = block_sum(cross[k], scratch); }
+            if (threadIdx.x == 0) { put_partial(partials, maxBlocks, PS_MOM_XN + k, a); put_partial(partials, maxBlocks, PS_CNT_XN + k, b); }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: exclusive prefix sum of the cell histogram (calc_firstAtomInCell cuSort.cu:130-143: 1 thread there)
+//     one 1024-thread workgroup; each thread owns a contiguous run of cells.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_cells(int nCell, const int32_t* __restrict__ cellCount, int32_t* __restrict__ cellStart,
+                                                     StepParams P, Counts* cnt, int slabMode)
+{
+    __shared__ int waveTot[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (nCell + 1023) / 1024;
+    const int b = tid * per, e = min(b + per, nCell);
+    int s = 0;
+    for (int c = b; c < e; c++) s += cellCount[c];
+    // inclusive scan of per-thread totals across the wave, then across waves
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, kWave); if (lane >= o) incl += n; }
+    if (lane == 63) waveTot[w] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; k++) base += waveTot[k];
+    int run = base + incl - s;
+    for (int c = b; c < e; c++) { cellStart[c] = run; run += cellCount[c]; }
+    if (tid == 1023)
+    {
+        int total = base + incl;
+        cellStart[nCell] = total;
+        cnt->nTotal = total;
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        // the atoms to be sorted are the old owned range plus whatever k_unpack appended behind it
+        cnt->srcBegin = cnt->ownedBegin;
+        cnt->srcEnd = cnt->ownedEnd + cnt->nRecv;
+        cnt->nRecv = 0;
+        if (slabMode)
+        {   // owned atoms = cells of the x-layers [hw, ncxLocal - hw): a contiguous range of the sorted arrays
+            const int plane = P.nc[1] * P.nc[2];
+            cnt->ownedBegin = cellStart[P.hw[0] * plane];
+            cnt->ownedEnd = cellStart[(P.ncxLocal - P.hw[0]) * plane];
+        }
+        else { cnt->ownedBegin = 0; cnt->ownedEnd = cellStart[nCell]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5a/K5b: counting-sort placement with a deterministic order inside each cell.
+//   k_place  : provisional slot (atomic arrival order) -> (id, source index) pairs grouped by cell
+//   k_rank_gather : rank of the atom's persistent id inside its cell -> final position; moves the state.
+//   (sort_atoms cuSort.cu:145-197 carries the arrival order, which differs run to run.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_place(const Counts* __restrict__ cnt,
+                                                  const int32_t* __restrict__ cellOf, const int32_t* __restrict__ slotOf,
+                                                  const int32_t* __restrict__ cellStart, const int32_t* __restrict__ idIn,
+                                                  int32_t* __restrict__ tmpId, int32_t* __restrict__ tmpSrc, int32_t* __restrict__ tmpCell)
+{
+    const int i = cnt->srcBegin + blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cnt->srcEnd) return;
+    const int c = cellOf[i];
+    const int p = cellStart[c] + slotOf[i];
+    tmpId[p] = idIn[i];
+    tmpSrc[p] = i;
+    tmpCell[p] = c;
+}
+
+__global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict__ cnt, const int32_t* __restrict__ cellStart,
+                                                        const int32_t* __restrict__ tmpId, const int32_t* __restrict__ tmpSrc,
+                                                        const int32_t* __restrict__ tmpCell, AtomArrays src, AtomArrays dst,
+                                                        int32_t* __restrict__ cellOfSorted, int carryForces)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= cnt->nTotal) return;
+    const int c = tmpCell[p];
+    const int s = cellStart[c], e = cellStart[c + 1];
+    const int myId = tmpId[p];
+    int rank = 0;
+    for (int q = s; q < e; q++) rank += (tmpId[q] < myId) ? 1 : 0;
+    const int d = s + rank;
+    const int i = tmpSrc[p];
+    dst.x[d] = src.x[i]; dst.y[d] = src.y[i]; dst.z[d] = src.z[i];
+    dst.vx[d] = src.vx[i]; dst.vy[d] = src.vy[i]; dst.vz[d] = src.vz[i];
+    dst.U[d] = src.U[i]; dst.rad[d] = src.rad[i];
+    dst.type[d] = src.type[i]; dst.id[d] = myId;
+    if (carryForces) { dst.fx[d] = src.fx[i]; dst.fy[d] = src.fy[i]; dst.fz[d] = src.fz[i]; }
+    cellOfSorted[d] = c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7/K8 (variant 1): per-atom gather over the neighbour-cell stencil.  Full (not half-shell) neighbour
+// evaluation: forces are written, never accumulated atomically; no pair tables (the reference's are
+// O(nCell^2) on the host, cuCellList.cu:516-531).  Correctness baseline for the tiled kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_pair_atom(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
+                                                      const Counts* __restrict__ cnt, const int32_t* __restrict__ cellStart,
+                                                      const int32_t* __restrict__ cellOfSorted, double* __restrict__ partials, int maxBlocks)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int i = cnt->ownedBegin + blockIdx.x * kBlock + threadIdx.x;
+    PairAcc acc = {0, 0, 0, 0, 0, 0};
+    if (i < cnt->ownedEnd)
+    {
+        const double xi = A.x[i], yi = A.y[i], zi = A.z[i];
+        const int ti = A.type[i];
+        const double radi = P.use_radii ? A.rad[i] : 0.0;
+        const int c = cellOfSorted[i];
+        const int cz = c % P.nc[2], cy = (c / P.nc[2]) % P.nc[1], lx = c / (P.nc[1] * P.nc[2]);
+        const double q = S.charge[ti];
+        acc.fx = -q * P.E[0]; acc.fy = -q * P.E[1]; acc.fz = -q * P.E[2];          // clear_force integrators.cpp:17-39
+        for (int ox = 0; ox < P.nOff[0]; ox++)
+        {
+            int nx;
+            if (P.nranks > 1) nx = lx + ox - P.hw[0];                                  // slab window: ghost layers are resident
+            else if (P.nOff[0] == P.nc[0]) nx = ox;
+            else { nx = lx + ox - P.hw[0]; if (nx < 0) nx += P.nc[0]; else if (nx >= P.nc[0]) nx -= P.nc[0]; }
+            for (int oy = 0; oy < P.nOff[1]; oy++)
+            {
+                int ny;
+                if (P.nOff[1] == P.nc[1]) ny = oy;
+                else { ny = cy + oy - P.hw[1]; if (ny < 0) ny += P.nc[1]; else if (ny >= P.nc[1]) ny -= P.nc[1]; }
+                // the z-neighbours of one (x, y) column are contiguous in the sorted arrays unless the run wraps
+                for (int oz = 0; oz < P.nOff[2]; oz++)
+                {
+                    int nz;
+                    if (P.nOff[2] == P.nc[2]) nz = oz;
+                    else { nz = cz + oz - P.hw[2]; if (nz < 0) nz += P.nc[2]; else if (nz >= P.nc[2]) nz -= P.nc[2]; }
+                    const int cn = (nx * P.nc[1] + ny) * P.nc[2] + nz;
+                    const int jb = cellStart[cn], je = cellStart[cn + 1];
+                    for (int j = jb; j < je; j++)
+                    {
+                        if (j == i) continue;
+                        double dx = xi - A.x[j], dy = yi - A.y[j], dz = zi - A.z[j];
+                        min_image(dx, P.L[0], P.half[0]); min_image(dy, P.L[1], P.half[1]); min_image(dz, P.L[2], P.half[2]);
+                        const double r2 = dx * dx + dy * dy + dz * dz;
+                        if (r2 <= P.r2Max)
+                            pair_visit(P, S, pots, dx, dy, dz, r2, ti, A.type[j], radi, P.use_radii ? A.rad[j] : 0.0, acc);
+                    }
+                }
+            }
+        }
+        A.fx[i] = acc.fx; A.fy[i] = acc.fy; A.fz[i] = acc.fz;
+    }
+    double s;
+    s = block_sum(acc.eV, scratch); if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EVDW, s);
+    s = block_sum(acc.eC, scratch); if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_ECOUL, s);
+    s = block_sum(acc.dropped, scratch); if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_DROPPED, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10: second half-kick + kinetic-energy partials (verlet_2stage cuMDfunc.cu:521-600 ; integrate2
+//      integrators.cpp:486-531).  Also clears the cell histogram for the next step (clear_clist).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_integrate2(StepParams P, SpecTable S, AtomArrays A, const Counts* __restrict__ cnt,
+                                                       int32_t* __restrict__ cellCount, int nCell, double* __restrict__ partials, int maxBlocks)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    for (int c = gid; c < nCell; c += gridDim.x * kBlock) cellCount[c] = 0;
+    const int i = cnt->ownedBegin + gid;
+    double kin = 0.0;
+    if (i < cnt->ownedEnd)
+    {
+        const int t = A.type[i];
+        const double rM = S.rMhdt[t];
+        double vx = A.vx[i] + rM * A.fx[i];
+        double vy = A.vy[i] + rM * A.fy[i];
+        double vz = A.vz[i] + rM * A.fz[i];
+        A.vx[i] = vx; A.vy[i] = vy; A.vz[i] = vz;
+        kin = (vx * vx + vy * vy + vz * vz) * S.mass[t];
+    }
+    double s = block_sum(kin, scratch);
+    if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EKIN, 0.5 * s);
+}
+
+// sum one partial slot over blocks in a fixed order (single workgroup)
+__device__ __forceinline__ double reduce_slot(const double* __restrict__ partials, int maxBlocks, int nBlocks, int slot, double* scratch)
+{
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nBlocks; b += blockDim.x) v += partials[(size_t)slot * maxBlocks + b];
+    return block_sum(v, scratch);
+}
+
+// equilibration scaling (integrate2 tScale branch integrators.cpp:511-522 ; temp_scale cuTemp.cu:77-113):
+// k_reduce_kin sums this rank's kinetic energy, k_scale_decision turns the all-rank value into the factor.
+__global__ __launch_bounds__(1024) void k_reduce_kin(StepParams P, const double* __restrict__ partials, int maxBlocks, int nBlocks, DevStats* st,
+                                                     double* __restrict__ ekOut)
+{
+    __shared__ double scratch[16];
+    double ek = reduce_slot(partials, maxBlocks, nBlocks, PS_EKIN, scratch);
+    if (threadIdx.x == 0) { st->local[PS_EKIN] = ek; ekOut[0] = ek; }
+}
+
+__global__ void k_scale_decision(StepParams P, DevStats* st, const double* __restrict__ ekGlobal)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long iStep = st->step + 1;                         // 1-based index of the step in flight (main.cpp:92)
+    const double ek = ekGlobal[0];
+    double k = 1.0;
+    if (P.nEq > 0 && iStep <= P.nEq && P.freqEq > 0 && (iStep % P.freqEq) == 0 && ek != 0.0)
+    {
+        const double c = (P.tstat == 2) ? 0.25 : 1.0;             // cuTemp.cu:90-94
+        k = sqrt(c * P.tKin / ek);
+        st->local[PS_EKIN] = P.tKin / (double)P.nranks;           // engKin := tKin (integrators.cpp:521, cuTemp.cu:112)
+    }
+    st->vscale = k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K11 + K12: velocity scaling (equilibration) and the radiative thermostat
+//   tstat_radi9 cuTemp.cu:689-773, adsorb_rand_photon :484-507, radiate_photon3 :631-685,
+//   get_angled_vector :395-453 - fp64, counter-based RNG, fixes of SURVEY Appendix C-9..C-12.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void angled_vector(const double v[3], double cos_phi, double theta, double out[3])
+{
+    const double l1 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    double v1[3] = {v[0] / l1, v[1] / l1, v[2] / l1}, v2[3], v3[3];
+    if (v1[0] != 0.0) { v2[1] = 1.0; v2[2] = 1.0; v2[0] = -(v1[1] * v2[1] + v1[2] * v2[2]) / v1[0]; }
+    else if (v1[1] != 0.0) { v2[0] = 1.0; v2[2] = 1.0; v2[1] = -(v1[2] * v2[2]) / v1[1]; }
+    else { v2[0] = 1.0; v2[1] = 0.0; v2[2] = 0.0; }
+    v3[0] = v1[1] * v2[2] - v1[2] * v2[1];
+    v3[1] = -v1[0] * v2[2] + v1[2] * v2[0];
+    v3[2] = v1[0] * v2[1] - v1[1] * v2[0];
+    const double l2 = sqrt(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2]);
+    const double l3 = sqrt(v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2]);
+    for (int k = 0; k < 3; k++) { v2[k] /= l2; v3[k] /= l3; }
+    const double sinPhi = sqrt(1 - cos_phi * cos_phi), sinTh = sin(theta), cosTh = cos(theta);
+    for (int k = 0; k < 3; k++) out[k] = v1[k] * cos_phi + sinPhi * (cosTh * v2[k] + sinTh * v3[k]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_post(StepParams P, SpecTable S, AtomArrays A, const Counts* __restrict__ cnt,
+                                                 const DevStats* __restrict__ st, const double* __restrict__ photons,
+                                                 const double* __restrict__ uvx, const double* __restrict__ uvy, const double* __restrict__ uvz,
+                                                 double* __restrict__ partials, int maxBlocks)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int i = cnt->ownedBegin + blockIdx.x * kBlock + threadIdx.x;
+    double uSum = 0.0;
+    if (i < cnt->ownedEnd)
+    {
+        const double k = st->vscale;
+        double vx = A.vx[i], vy = A.vy[i], vz = A.vz[i];
+        if (k != 1.0) { vx *= k; vy *= k; vz *= k; }
+        if (P.tstat == 2)
+        {
+            const uint64_t step = (uint64_t)(st->step + 1);
+            const uint64_t id = (uint64_t)A.id[i];
+            const int tp = A.type[i];
+            const double m = S.mass[tp];
+            double U = A.U[i];
+            const double pe = photons[(id + step) % (uint64_t)P.nAtGlobal];
+            {   // absorb
+                const uint32_t rnd = rng_draw(P.seed, step, id, 1) % 3072u;
+                const double v02 = vx * vx + vy * vy + vz * vz;
+                const double ermc = pe * P.revLight / m;
+                vx += ermc * uvx[rnd]; vy += ermc * uvy[rnd]; vz += ermc * uvz[rnd];
+                const double v12 = vx * vx + vy * vy + vz * vz;
+                U += pe + 0.5 * m * (v02 - v12);
+            }
+            if (U > P.radThr)
+            {   // radiate
+                const double u0 = U;
+                const double v[3] = {vx, vy, vz};
+                const double v02 = vx * vx + vy * vy + vz * vz, v0 = sqrt(v02);
+                const double ph = P.radFrac * u0;
+                const double ermc = ph * P.revLight / m;
+                double d[3];
+                if (v0 == 0.0)
+                {
+                    const uint32_t rnd = rng_draw(P.seed, step, id, 2) % 3072u;
+                    d[0] = uvx[rnd]; d[1] = uvy[rnd]; d[2] = uvz[rnd];
+                }
+                else
+                {
+                    const double ermcv0 = ermc / v0;
+                    if (ermcv0 >= 1.0) { d[0] = -v[0] / v0; d[1] = -v[1] / v0; d[2] = -v[2] / v0; }
+                    else
+                    {
+                        const uint32_t r1 = rng_draw(P.seed, step, id, 2) % 2048u;
+                        double cos_phi = (double)r1 / 1024.0 * (1.0 - ermcv0);
+                        cos_phi -= 1.0;
+                        const uint32_t r2 = rng_draw(P.seed, step, id, 3) % 2048u;
+                        const double theta = (double)r2 / 1024.0 * P.numPi;
+                        angled_vector(v, cos_phi, theta, d);
+                    }
+                }
+                vx += ermc * d[0]; vy += ermc * d[1]; vz += ermc * d[2];
+                const double v12 = vx * vx + vy * vy + vz * vz;
+                U -= (ph + 0.5 * m * (v12 - v02));
+            }
+            const double restrE = U < S.mxEng[tp] ? U : S.mxEng[tp];
+            A.rad[i] = S.radA[tp] / (S.radB[tp] - restrE);
+            A.U[i] = U;
+            uSum = U;
+        }
+        A.vx[i] = vx; A.vy[i] = vy; A.vz[i] = vz;
+    }
+    double s = block_sum(uSum, scratch);
+    if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_ETEMP, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 + K13: fold the per-block partials into this rank's per-step sums (fixed order)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_collect(const double* __restrict__ partials, int maxBlocks, int nBlocksAtoms, int nBlocksPair,
+                                                  DevStats* st, unsigned slotMask)
+{
+    __shared__ double scratch[16];
+    for (int slot = 0; slot < PS_COUNT; slot++)
+    {
+        if (!((slotMask >> slot) & 1u)) continue;
+        const int nb = (slot == PS_EVDW || slot == PS_ECOUL || slot == PS_DROPPED) ? nBlocksPair : nBlocksAtoms;
+        double v = reduce_slot(partials, maxBlocks, nb, slot, scratch);
+        if (threadIdx.x == 0) st->local[slot] = v;
+        __syncthreads();
+    }
+}
+
+// reset_quantities + calc_quantities (cuMDfunc.cu:270, main.cu:121-194 ; serial calc_chars integrators.cpp:63-73).
+// Works on this rank's sums; the cross-rank sum is taken when the host asks for statistics (Engine::get_stats).
+__global__ void k_finalize(StepParams P, DevStats* st, int advance)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double* sums = st->local;
+    st->engElecField = sums[PS_EFIELD];
+    st->engVdW = sums[PS_EVDW];
+    st->engCoul = sums[PS_ECOUL];
+    st->engKin = sums[PS_EKIN];
+    st->engTemp = sums[PS_ETEMP];
+    for (int k = 0; k < 6; k++)
+    {
+        st->mom[k] += sums[PS_MOM_XN + k];
+        st->cross[k] += (long long)(sums[PS_CNT_XN + k] + 0.5);
+    }
+    st->dropped += (long long)(sums[PS_DROPPED] + 0.5);
+    st->temperature = 2.0 * st->engKin * P.revDegFree * P.rkB;
+    st->engPot = st->engCoul + st->engVdW;
+    st->engTot = st->engElecField + st->engVdW + st->engCoul + st->engKin;
+    if (advance) st->step += 1;
+}
+
+}  // namespace aztot

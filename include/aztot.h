@@ -1,0 +1,176 @@
+/* aztot.h - C ABI of the MI355X-native azTotMD per-step hot path.
+ *
+ * The reference (raadyn/aztotmd) has no plugin/FFI interface: its hot path is the set of free
+ * functions and kernels that main.cu calls on one opaque device struct.  Each entry point below
+ * names the reference interface it replaces (paths relative to the reference's src/).
+ * Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * All functions return AZTOT_OK (0) on success and a negative code on failure;
+ * aztot_last_error() returns a human readable message for the calling thread.
+ * A handle is single-threaded (as the reference: one host thread, main.cu:239).
+ *
+ * Units everywhere: Angstrom, ps, eV, e; masses in amu at this boundary (the reference's input units,
+ * const.h:17-49).
+ */
+#ifndef AZTOT_H
+#define AZTOT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZTOT_OK 0
+#define AZTOT_ERR_IO -1          /* cannot open / parse an input file (reference: printf("ERROR[..]") + return 0) */
+#define AZTOT_ERR_INPUT -2       /* semantically invalid or out-of-scope input */
+#define AZTOT_ERR_DEVICE -3      /* HIP runtime error / no device */
+#define AZTOT_ERR_ARG -4
+#define AZTOT_ERR_COMM -5
+
+/* pair potential ids: vdw.h:15-21 */
+enum { AZTOT_VDW_LJ = 1, AZTOT_VDW_BUCK = 2, AZTOT_VDW_746 = 3, AZTOT_VDW_BHM = 4, AZTOT_VDW_ELIN = 5, AZTOT_VDW_EINV = 6, AZTOT_VDW_SURK = 7 };
+/* electrostatics: elec.h:8-12 */
+enum { AZTOT_ELEC_NONE = 0, AZTOT_ELEC_DIRECT = 1, AZTOT_ELEC_EWALD = 2, AZTOT_ELEC_FENNEL = 3 };
+/* thermostats: temperature.h:10-12 */
+enum { AZTOT_TSTAT_NONE = 0, AZTOT_TSTAT_NOSE = 1, AZTOT_TSTAT_RADI = 2 };
+/* init_vel: dataStruct.h:7-10 */
+enum { AZTOT_VEL_ZERO = 0, AZTOT_VEL_GAUSS = 1, AZTOT_VEL_CONST = 2, AZTOT_VEL_KENG = 3 };
+
+typedef struct aztot_model aztot_model;   /* host model: Atoms+Field+Sim+Elec+TStat+Box of dataStruct.h */
+typedef struct aztot_md aztot_md;         /* device state: cudaMD + hostManagMD of cuStruct.h:81-423 */
+
+/* one line of the 'spec' section of field.txt (sys_init.cpp:83) + its 'radii' line (sys_init.cpp:468-480) */
+typedef struct
+{
+    char name[8];
+    double mass_amu, charge;
+    int32_t frozen;              /* 'frozensp' section, sys_init.cpp:241-255 */
+    double radA, radB, mxEng;
+} aztot_species;
+
+/* one line of the 'vdw' section of field.txt (vdw.cpp:244): raw user parameters */
+typedef struct
+{
+    int32_t spec_a, spec_b, type;
+    double rcut;
+    double p[5];
+} aztot_vdw;
+
+/* the directives of control.txt that touch the hot path (sys_init.cpp:676-989) */
+typedef struct
+{
+    double timestep;             /* ps */
+    int32_t nstep, nequil, eqfreq;
+    double temperature;          /* K */
+    int32_t tstat_type;          /* AZTOT_TSTAT_* */
+    double tstat_tau;            /* 'nose tau' */
+    int32_t elec_type;           /* AZTOT_ELEC_* */
+    double r_real, alpha;        /* elec cut-off, Ewald/Fennell alpha */
+    int32_t init_vel;            /* AZTOT_VEL_* */
+    double init_vel_par[3];      /* const vx vy vz | keng e */
+    double elecfield[3];         /* dU/dx, dU/dy, dU/dz */
+    int32_t use_cell_list;       /* 'cell_list' present */
+    double cell_list;            /* desired cell edge */
+    int32_t stat;                /* statistics period */
+} aztot_control;
+
+/* array form of atoms.xyz + field.txt + control.txt (used by tests / bench; same state as aztot_init_md) */
+typedef struct
+{
+    int32_t n_atoms, n_species, n_vdw;
+    double box[3];
+    const int32_t *types;
+    const double *x, *y, *z, *vx, *vy, *vz;   /* vx..vz may be NULL (zeros) */
+    const aztot_species *species;
+    const aztot_vdw *vdw;
+    aztot_control control;
+} aztot_system;
+
+/* run-time switches that replace the reference's compile-time defines.h and its two mains' differences */
+typedef struct
+{
+    int32_t device;              /* HIP device ordinal (reference: device 0 hard-coded, cuInit.cu:688) */
+    int32_t initial_forces;      /* 1: forces of the initial configuration are computed at init (serial path,
+                                       sys_init.cpp:1181-1184); 0: start from F = 0 (GPU path, sys_init.cpp:551-553) */
+    int32_t center_box;          /* 1: apply center_box at init (serial path only, sys_init.cpp:1145) */
+    uint64_t seed;               /* seed of the counter-based RNG (thermostat, tables, init_vel) */
+    int32_t pair_variant;        /* 0: auto; 1: per-atom gather kernel; 2: LDS-tiled wave-per-cell kernel */
+    double cell_size;            /* 0: derive from control.cell_list / cut-off; >0: force this cell edge */
+    int32_t use_graph;           /* 1: replay the step as a captured hipGraph when possible */
+    int32_t profile;             /* 1: time every kernel with HIP events (aztot_kernel_times) */
+    int32_t reserved[8];
+} aztot_options;
+
+/* per-step scalars: the fields tracked by stat.dat (cuStat.cu:241-261) + serial calc_chars (integrators.cpp:63-73) */
+typedef struct
+{
+    int64_t step;                /* number of completed steps */
+    double time;                 /* ps */
+    double engTot, engKin, engVdW, engCoul, engElecField, engTemp, engPot;
+    double temperature;          /* 2 engKin / (degFree kB) */
+    double posMom[3], negMom[3]; /* wall momentum accumulators (box.cpp:230-295; cuMDfunc.cu:72-106) */
+    int64_t posCross[3], negCross[3];
+    double pressure;             /* from wall momentum over the last 'stat' window (main.cpp:146-152) */
+    int64_t pairs_dropped;       /* pairs skipped by the |f|^2 > 1e10 rule (integrators.cpp:170) */
+    int64_t n_cells;
+} aztot_stats;
+
+/* host copy of the per-atom state, fp64 SoA, in ORIGINAL atom order (id order); any pointer may be NULL */
+typedef struct
+{
+    int32_t n_atoms;
+    double *x, *y, *z, *vx, *vy, *vz, *fx, *fy, *fz, *U, *radius;
+    int32_t *types;
+} aztot_state;
+
+/* ---- host model: replaces init_md / free_md (sys_init.h:11,17) ------------------------------------- */
+/* reads atoms.xyz, field.txt, control.txt, cuda.txt from `dir` (reference: from the cwd) */
+int aztot_init_md(const char *dir, aztot_model **out);
+int aztot_model_create(const aztot_system *sys, aztot_model **out);
+/* string-keyed read-out of parsed/derived values as doubles; returns the number of values written
+   (or needed, if cap is too small), negative on unknown key.  Keys: see aztotmd_amd/csrc/capi.cpp */
+int aztot_model_query(const aztot_model *m, const char *key, double *out, int cap);
+void aztot_free_md(aztot_model *m);
+
+/* ---- device: replaces init_cudaMD / md_to_host / free_device_md (cuInit.h:4,6,7) --------------------- */
+void aztot_default_options(aztot_options *opt);
+int aztot_init_device(const aztot_model *m, const aztot_options *opt, aztot_md **out);
+void aztot_free_device(aztot_md *md);
+
+/* ---- the hot path ----------------------------------------------------------------------------------- */
+/* n iterations of the loop body of main.cu:281-410 (reset_quantities, verlet_1stage, iter_fastCellList,
+   verlet_2stage, apply_tstat, calc_quantities) with the serial path's fp64 arithmetic */
+int aztot_step(aztot_md *md, int nsteps);
+/* cell-list build + sort + pair forces for the current positions: iter_fastCellList (cuPairs.h:8) alone */
+int aztot_forces(aztot_md *md);
+int aztot_get_stats(aztot_md *md, aztot_stats *out);
+int aztot_md_to_host(aztot_md *md, aztot_state *out);
+int aztot_set_state(aztot_md *md, const aztot_state *in);
+
+/* ---- measurement ------------------------------------------------------------------------------------ */
+/* per-kernel HIP-event times accumulated since the last reset (options.profile = 1).
+   names: NUL-separated list written into `names` (cap bytes); ms / calls: arrays of length >= returned count */
+int aztot_kernel_times(aztot_md *md, char *names, int cap, double *ms, int64_t *calls, int max_kernels);
+int aztot_reset_kernel_times(aztot_md *md);
+
+/* ---- multi-GPU slab decomposition (one process per GPU) ---------------------------------------------- */
+/* size of the opaque RCCL unique id; rank 0 creates it, the launcher broadcasts it (e.g. torch.distributed) */
+int aztot_comm_id_bytes(void);
+int aztot_comm_make_id(void *id_bytes);
+/* host-staged exchange callback for tests without RCCL (gloo): send `sbytes` to `peer`, receive into rbuf */
+typedef int (*aztot_sendrecv_fn)(void *ctx, int send_peer, const void *sbuf, int64_t sbytes,
+                                 int recv_peer, void *rbuf, int64_t rcap, int64_t *rbytes);
+typedef int (*aztot_allreduce_fn)(void *ctx, double *buf, int n);
+/* as aztot_init_device, but this rank owns slab `rank` of `nranks` along x; exactly one of id_bytes / callbacks is used */
+int aztot_init_device_slab(const aztot_model *m, const aztot_options *opt, int rank, int nranks,
+                           const void *rccl_id_bytes, aztot_sendrecv_fn sendrecv, aztot_allreduce_fn allreduce, void *ctx,
+                           aztot_md **out);
+
+const char *aztot_last_error(void);
+const char *aztot_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZTOT_H */

@@ -1,0 +1,252 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP hot path, called through the C ABI, against the
+CPU oracle (oracle/, a restatement of the reference's serial path pinned to the reference's own compiled code)
+and against the committed golden vectors that the reference binary generated.
+
+Tolerances (fp64): forces/positions/velocities <= 1e-11 array-relative after a force evaluation, <= 1e-9 after
+tens of steps (north star: 1e-9); energies <= 1e-12 relative.  Differences come only from summation order and
+FMA contraction; the arithmetic per pair follows the serial reference.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from aztotmd_amd import api, inputs
+from oracle import oracle
+from util import mixed_case, rel_err
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EKEYS = ("engVdW", "engElec3", "engKin", "engTot", "engElecField", "Temp", "momXn", "momXp", "momYn", "momYp", "momZn", "momZp")
+FKEYS = ("fx", "fy", "fz")
+
+
+def engine(case, **kw):
+    return api.Engine(api.Model.from_case(case), **kw)
+
+
+def check_forces(case, tol=1e-11, **kw):
+    o = oracle.Oracle(case)
+    o.forces(0)
+    so, sto = o.state(), o.stats()
+    e = engine(case, **kw)
+    s, st = e.state(), e.stats()
+    for k in FKEYS:
+        assert rel_err(s[k], so[k]) < tol, (k, rel_err(s[k], so[k]))
+    assert abs(st["engVdW"] - sto["engVdW"]) <= 1e-12 * abs(sto["engVdW"]) + 1e-14
+    assert abs(st["engCoul"] - sto["engElec3"]) <= 1e-12 * abs(sto["engElec3"]) + 1e-14
+    return e, o
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("name", ["F1", "F2", "F3"])
+def test_initial_forces_match_oracle(name, variant):
+    check_forces(inputs.config(name), pair_variant=variant)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("pot", ["buck", "bmhs", "p746", "elin", "einv", "lnjs+dir", "lnjs+fenn+field"])
+def test_potential_families(pot, variant):
+    check_forces(mixed_case(pot), pair_variant=variant)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("cell", [2.2, 3.3, 4.7, 13.0])
+def test_cells_smaller_or_larger_than_cutoff(cell, variant):
+    """control.txt 'cell_list' below the cut-off (case study 2: 2.7 vs rc 6.0) widens the stencil; above it, coarsens."""
+    check_forces(inputs.config("F1"), pair_variant=variant, cell_size=cell)
+
+
+def test_golden_trajectory_F1():
+    """50 steps against the reference binary's own trajectory (tests/golden/F1_lj.npz)."""
+    z = np.load(os.path.join(G, "F1_lj.npz"))
+    case = inputs.config("F1")
+    for k in ("x", "y", "z"):
+        assert np.array_equal(case[k], z["in_" + k])
+    e = engine(case)
+    done = 0
+    for st in (0, 1, 10, 50):
+        e.step(st - done)
+        done = st
+        s, stt = e.state(), e.stats()
+        ref = dict(zip(EKEYS, z["e_%d" % st].tolist()))
+        for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+            assert rel_err(s[k], z["%s_%d" % (k, st)]) < 1e-10, (st, k, rel_err(s[k], z["%s_%d" % (k, st)]))
+        assert abs(stt["engVdW"] - ref["engVdW"]) < 1e-12 * abs(ref["engVdW"])
+        if st:
+            assert abs(stt["engKin"] - ref["engKin"]) < 1e-11 * abs(ref["engKin"])
+            assert abs(stt["engTot"] - ref["engTot"]) < 1e-12 * abs(ref["engTot"])
+            assert abs(stt["temperature"] - ref["Temp"]) < 1e-11 * abs(ref["Temp"])
+
+
+@pytest.mark.parametrize("name,kw", [("F2_lj", {}), ("F3_fennel", dict(charges=(0.2, -0.2), elec="fenn"))])
+def test_golden_trajectory_4000(name, kw):
+    z = np.load(os.path.join(G, name + ".npz"))
+    case = inputs.lj_case((10, 10, 10), a=5.26, seed=12345, **kw)
+    e = engine(case)
+    s = e.state()
+    for k in FKEYS:
+        assert rel_err(s[k], z[k + "_0"]) < 1e-11
+    e.step(50)
+    s, st = e.state(), e.stats()
+    ref = dict(zip(EKEYS, z["e_50"].tolist()))
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(s[k], z[k + "_50"]) < 1e-9, (k, rel_err(s[k], z[k + "_50"]))
+    for a, b in (("engVdW", "engVdW"), ("engCoul", "engElec3"), ("engKin", "engKin"), ("engTot", "engTot")):
+        assert abs(st[a] - ref[b]) <= 1e-11 * abs(ref[b]) + 1e-13, (a, st[a], ref[b])
+
+
+def test_golden_equilibration_scaling():
+    """nequil 20 / eqfreq 5: the velocity rescaling branch of integrate2 (integrators.cpp:511-522)."""
+    z = np.load(os.path.join(G, "F1_tscale.npz"))
+    case = inputs.config("F1")
+    case.update(nEq=20, freqEq=5, T=85.0)
+    for k in ("vx", "vy", "vz"):
+        case[k] = z["in_" + k]
+    e = engine(case)
+    e.step(5)
+    s, st = e.state(), e.stats()
+    ref = dict(zip(EKEYS, z["e_5"].tolist()))
+    assert abs(st["engKin"] - ref["engKin"]) < 1e-12 * ref["engKin"]
+    for k in ("vx", "x", "fx"):
+        assert rel_err(s[k], z[k + "_5"]) < 1e-10
+    e.step(25)
+    s, st = e.state(), e.stats()
+    ref = dict(zip(EKEYS, z["e_30"].tolist()))
+    for k in ("vx", "vy", "vz", "x", "fz"):
+        assert rel_err(s[k], z[k + "_30"]) < 1e-9
+    assert abs(st["engTot"] - ref["engTot"]) < 1e-11 * abs(ref["engTot"])
+
+
+def test_wall_crossing_counters_and_field():
+    """hot gas: atoms cross the periodic walls; wall momenta, crossing counts and field energy vs the oracle."""
+    case = mixed_case("lnjs+fenn+field", vel_T=3000.0)
+    o = oracle.Oracle(case)
+    o.forces(0)
+    o.step(40)
+    e = engine(case)
+    e.step(40)
+    st, sto = e.stats(), o.stats()
+    assert sum(sto["cross"]) > 20
+    assert [st["negCross"][0], st["posCross"][0], st["negCross"][1], st["posCross"][1], st["negCross"][2], st["posCross"][2]] == sto["cross"]
+    mom = [st["negMom"][0], st["posMom"][0], st["negMom"][1], st["posMom"][1], st["negMom"][2], st["posMom"][2]]
+    ref = [sto[k] for k in ("momXn", "momXp", "momYn", "momYp", "momZn", "momZp")]
+    assert rel_err(mom, ref) < 1e-11
+    assert abs(st["engElecField"] - sto["engElecField"]) < 1e-11 * abs(sto["engElecField"])
+    s, so = e.state(), o.state()
+    for k in ("x", "vx", "fz"):
+        assert rel_err(s[k], so[k]) < 1e-9
+    for k in ("x", "y", "z"):
+        assert s[k].min() >= 0.0 and (s[k] < np.array(case["box"])["xyz".index(k)]).all()
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_radiative_thermostat_matches_oracle(variant):
+    """tstat_radi9 restated with the counter RNG: GPU vs CPU oracle, incl. photon table, U and radii."""
+    case = inputs.lj_case((5, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5, T=298.0, tstat="radi", vel_T=150.0,
+                          radii=[(2.73, 4.731, 0.2)], nEq=10, freqEq=5)
+    o = oracle.Oracle(case)
+    o.forces(0)
+    e = engine(case, pair_variant=variant)
+    ph = e.model.query("photons", seed=12345)
+    assert np.array_equal(ph, o.photons())
+    assert np.allclose(e.state()["radius"], o.state()["rad"], rtol=0, atol=0)
+    for nst in (1, 9, 20):
+        o.step(nst)
+        e.step(nst)
+        s, so, st, sto = e.state(), o.state(), e.stats(), o.stats()
+        for a, b in (("vx", "vx"), ("vy", "vy"), ("vz", "vz"), ("x", "x"), ("U", "U"), ("radius", "rad"), ("fx", "fx")):
+            assert rel_err(s[a], so[b]) < 1e-9, (nst, a, rel_err(s[a], so[b]))
+        assert abs(st["engTemp"] - sto["engTemp"]) <= 1e-10 * abs(sto["engTemp"])
+        assert abs(st["engKin"] - sto["engKin"]) <= 1e-10 * abs(sto["engKin"])
+    assert so["U"].max() > 1e-4          # the radiate branch was exercised
+
+
+def test_surk_radius_potential_with_thermostat():
+    """'surk' radius-dependent potential fed by the thermostat's radii (case study 2 style), GPU vs oracle."""
+    pos, box = inputs.fcc_positions((6, 6, 6), 5.8, 0.1, 5)
+    N = len(pos)
+    case = {"box": box.tolist(), "dt": 0.001, "species": [(39.9, 0.0)], "names": ["Ar"], "types": np.zeros(N, dtype=np.int32),
+            "vdw": [(0, 0, 7, 6.0, [75.0, 8.0, 1.0, 1.0])], "radii": [(2.73, 4.731, 0.2)], "x": pos[:, 0].copy(), "y": pos[:, 1].copy(),
+            "z": pos[:, 2].copy(), "vx": np.zeros(N), "vy": np.zeros(N), "vz": np.zeros(N), "T": 500.0, "tstat_type": 2,
+            "cell_list": 2.7, "use_clist": 1, "elec_type": 0}
+    o = oracle.Oracle(case)
+    o.forces(0)
+    e = engine(case)
+    for nst in (0, 5, 25):
+        o.step(nst)
+        e.step(nst)
+        s, so = e.state(), o.state()
+        for a, b in (("fx", "fx"), ("fy", "fy"), ("vz", "vz"), ("U", "U"), ("radius", "rad")):
+            assert rel_err(s[a], so[b]) < 1e-9, (nst, a, rel_err(s[a], so[b]))
+        assert abs(e.stats()["engVdW"] - o.stats()["engVdW"]) <= 1e-10 * abs(o.stats()["engVdW"])
+
+
+def test_input_files_round_trip(tmp_path):
+    """atoms.xyz / field.txt / control.txt / cuda.txt written in the reference grammar give the same run."""
+    case = inputs.config("F3")
+    case["nsteps"] = 7
+    inputs.write_input_files(case, str(tmp_path))
+    e1 = api.Engine(api.Model.from_dir(str(tmp_path)))
+    e2 = engine(case)
+    e1.step(7)
+    e2.step(7)
+    s1, s2 = e1.state(), e2.state()
+    for k in ("x", "vx", "fx", "fy"):
+        assert np.array_equal(s1[k], s2[k])
+
+
+def test_dilute_gas_is_force_free():
+    """case study 1 character: no pair inside the cut-off -> forces and energies exactly 0."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    n = 12
+    g = (np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3) + 0.5) * 30.0 + rng.uniform(-5, 5, (n ** 3, 3))
+    N = len(g)
+    case = {"box": [360.0] * 3, "dt": 0.001, "species": [(39.9, 0.0)], "names": ["Ar"], "types": np.zeros(N, dtype=np.int32),
+            "vdw": [(0, 0, 1, 4.0, [0.01006, 3.3952])], "x": g[:, 0].copy(), "y": g[:, 1].copy(), "z": g[:, 2].copy(),
+            "vx": np.zeros(N), "vy": np.zeros(N), "vz": np.zeros(N), "T": 298.0, "cell_list": 85.0, "use_clist": 1, "elec_type": 3,
+            "rReal": 8.0, "alpha": 0.4}
+    e = engine(case)
+    e.step(5)
+    s, st = e.state(), e.stats()
+    assert all(np.all(s[k] == 0.0) for k in FKEYS) and st["engVdW"] == 0.0 and st["engTot"] == 0.0
+    assert np.array_equal(s["x"], case["x"])
+
+
+def test_bitwise_reproducible_and_graph_equals_eager():
+    """id-ordered cells make the result independent of atomic arrival order; hipGraph replay == eager launches."""
+    case = inputs.config("F2")
+    runs = []
+    for kw in (dict(use_graph=1), dict(use_graph=0), dict(use_graph=1)):
+        e = engine(case, **kw)
+        e.step(21)
+        runs.append(e.state())
+    for k in ("x", "vx", "fx", "fz"):
+        assert np.array_equal(runs[0][k], runs[1][k]) and np.array_equal(runs[0][k], runs[2][k])
+
+
+def test_tile_and_atom_kernels_agree_bitwise_on_energy_scale():
+    case = inputs.config("F3")
+    a, b = engine(case, pair_variant=1), engine(case, pair_variant=2)
+    sa, sb = a.state(), b.state()
+    for k in FKEYS:
+        assert rel_err(sa[k], sb[k]) < 1e-13
+
+
+def test_c2_40k_energy_conservation_and_newton3():
+    """BASELINE config 2 (40 000 Ar, rc 8.5): size-independent properties at full size + oracle forces."""
+    case = inputs.config("C2")
+    e = engine(case)
+    s = e.state()
+    for k in FKEYS:
+        assert abs(s[k].sum()) < 1e-9            # Newton 3: sum of forces vanishes
+    o = oracle.Oracle(case)
+    o.forces(1)
+    so = o.state()
+    for k in FKEYS:
+        assert rel_err(s[k], so[k]) < 1e-11
+    e0 = e.stats()["engVdW"]
+    e.step(200)
+    st = e.stats()
+    assert abs(st["engTot"] - e0) < 2e-4 * abs(e0)      # NVE drift over 200 fs from a cold jittered lattice (unshifted cut-off)
+    assert st["pairs_dropped"] == 0
