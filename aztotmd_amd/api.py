@@ -209,13 +209,14 @@ class Engine:
     """Device state + step driver (reference: cudaMD + the loop body of main.cu:281-410)."""
 
     def __init__(self, model, device=0, initial_forces=1, center_box=0, seed=12345, pair_variant=0, cell_size=0.0, use_graph=1,
-                 profile=0, slab=None):
+                 profile=0, slab=None, debug=0):
         """slab: None or dict(rank=, nranks=, rccl_id=bytes) or dict(rank=, nranks=, sendrecv=callable, allreduce=callable)."""
         L = lib()
         o = _Options()
         L.aztot_default_options(C.byref(o))
         o.device, o.initial_forces, o.center_box, o.seed = device, initial_forces, center_box, seed
         o.pair_variant, o.cell_size, o.use_graph, o.profile = pair_variant, cell_size, use_graph, profile
+        o.reserved[0] = debug
         self.model = model
         self.N = int(model.query("n_atoms")[0])
         self.h = C.c_void_p()

@@ -73,6 +73,7 @@ private:
     std::vector<void*> allocs_;
     DevPot* dPots_ = nullptr;
     int32_t *dCellOf_ = nullptr, *dSlotOf_ = nullptr, *dCellCount_ = nullptr, *dCellStart_ = nullptr;
+    int32_t* dChunkTot_ = nullptr;
     int32_t *dTmpId_ = nullptr, *dTmpSrc_ = nullptr, *dTmpCell_ = nullptr, *dCellOfSorted_ = nullptr;
     double* dPartials_ = nullptr;
     DevStats* dStats_ = nullptr;

@@ -145,6 +145,7 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
     P_.numPi = 3.14159;         // cuTemp.cu:228
     P_.seed = opt_.seed;
     P_.rank = rank_; P_.nranks = nranks_;
+    P_.pad0 = opt_.reserved[0];
     P_.use_radii = 0;
     for (const auto& p : m.pairpots) if (p.type && p.use_radii) P_.use_radii = 1;
     P_.single_lj = (m.nSpec() == 1 && m.pairpots[0].type == AZTOT_VDW_LJ && m.elec_type == AZTOT_ELEC_NONE) ? 1 : 0;
@@ -217,6 +218,7 @@ void Engine::allocate()
         HIP_CHECK(hipMemcpy(dStats_, &zero, sizeof(DevStats), hipMemcpyHostToDevice));
     }
     dCounts_ = (Counts*)alloc(sizeof(Counts));
+    dChunkTot_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)(div_up(nCellAlloc_, kScanChunk) + 1));
     dEkGlobal_ = (double*)alloc(sizeof(double) * 2);
     if (nranks_ > 1)
     {
@@ -341,8 +343,10 @@ void Engine::sort_and_forces(bool integrate_first)
         });
     }
     if (nranks_ > 1) exchange_halo();
+    const int nChunks = div_up(P_.nCellLocal, kScanChunk);
     timed("scan_cells", [&] {
-        hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, stream_, P_.nCellLocal, dCellCount_, dCellStart_, P_, dCounts_, nranks_ > 1 ? 1 : 0);
+        hipLaunchKernelGGL(k_scan_totals, dim3(nChunks), dim3(kBlock), 0, stream_, P_.nCellLocal, dCellCount_, dChunkTot_);
+        hipLaunchKernelGGL(k_scan_apply, dim3(nChunks), dim3(kBlock), 0, stream_, P_.nCellLocal, dCellCount_, dChunkTot_, dCellStart_, dCounts_);
     });
     timed("place", [&] {
         hipLaunchKernelGGL(k_place, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellOf_, dSlotOf_, dCellStart_, cur().id, dTmpId_, dTmpSrc_,
@@ -350,7 +354,7 @@ void Engine::sort_and_forces(bool integrate_first)
     });
     timed("rank_gather", [&] {
         hipLaunchKernelGGL(k_rank_gather, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellStart_, dTmpId_, dTmpSrc_, dTmpCell_, cur(), oth(),
-                           dCellOfSorted_, 0);
+                           dCellOfSorted_, 0, P_, dCounts_);
     });
     cur_ ^= 1;
     launch_pair();
@@ -359,7 +363,7 @@ void Engine::sort_and_forces(bool integrate_first)
 void Engine::collect_and_finalize(unsigned slotMask, bool advance)
 {
     timed("collect", [&] {
-        hipLaunchKernelGGL(k_collect, dim3(1), dim3(1024), 0, stream_, dPartials_, maxBlocks_, div_up(capacity_, kBlock), pairBlocksUsed_, dStats_, slotMask);
+        hipLaunchKernelGGL(k_collect, dim3(PS_COUNT), dim3(1024), 0, stream_, dPartials_, maxBlocks_, div_up(capacity_, kBlock), pairBlocksUsed_, dStats_, slotMask);
     });
     timed("finalize", [&] { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, stream_, P_, dStats_, advance ? 1 : 0); });
 }

@@ -4,7 +4,7 @@
 //  ---------------------------------------------------   ----------------------------------------------
 //  clear_clist            cuMDfunc.cu:693                folded into k_integrate2 (zeroes the histogram)
 //  verlet_1stage+count_cell cuMDfunc.cu:333, cuSort.cu:114  k_integrate1_bin
-//  calc_firstAtomInCell   cuSort.cu:130 (1 thread)       k_scan_cells (one 1024-thread workgroup)
+//  calc_firstAtomInCell   cuSort.cu:130 (1 thread)       k_scan_totals + k_scan_apply (chunked, parallel)
 //  sort_atoms+refresh_arrays cuSort.cu:145,74            k_place + k_rank_gather (deterministic order)
 //  cell_list5a + cell_list4b_noshared + pair_1           k_pair_atom / k_pair_tile (no atomics, no tables)
 //     cuPairs.cu:2266,1474,117
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
     const int begin = cnt->ownedBegin, end = cnt->ownedEnd;
     const int i = begin + blockIdx.x * kBlock + threadIdx.x;
     double eField = 0.0, mom[6] = {0, 0, 0, 0, 0, 0}, cross[6] = {0, 0, 0, 0, 0, 0};
-    int anyCross = 0;
+    int anyCross = 0, myCell = 0;
     if (i < end)
     {
         const int t = A.type[i];
@@ -249,13 +249,30 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
             A.x[i] = x; A.y[i] = y; A.z[i] = z;
             eField = S.charge[t] * (x * P.E[0] + y * P.E[1] + z * P.E[2]);      // integrators.cpp:374 / cuMDfunc.cu:476
         }
-        const int c = local_cell(P, x, y, z);
-        cellOf[i] = c;
-        slotOf[i] = atomicAdd(&cellCount[c], 1);
+        myCell = local_cell(P, x, y, z);
+        cellOf[i] = myCell;
+    }
+    {
+        // histogram with one atomic per RUN of equal cells inside the wave: the arrays are still in the previous
+        // step's cell order, so neighbouring lanes mostly fall into the same cell (about 13 atoms per run)
+        const int lane = threadIdx.x & 63;
+        const int key = (i < end) ? myCell : -1 - lane;
+        const int prevKey = __shfl_up(key, 1, kWave);
+        const bool head = (lane == 0) || (key != prevKey);
+        const unsigned long long H = __ballot(head);
+        const unsigned long long upto = (lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL);
+        const int start = 63 - __clzll((long long)(H & upto));
+        const unsigned long long above = H & ~upto;
+        const int next = above ? (__ffsll((long long)above) - 1) : 64;
+        int base = 0;
+        if (head && i < end) base = atomicAdd(&cellCount[myCell], next - start);
+        base = __shfl(base, start, kWave);
+        if (i < end) slotOf[i] = base + (lane - start);
     }
     if (INTEGRATE)
     {
-        double s = block_sum(eField, scratch);
+        double s = 0.0;
+        if (P.E[0] != 0.0 || P.E[1] != 0.0 || P.E[2] != 0.0) s = block_sum(eField, scratch);
         if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EFIELD, s);
         const int blockCross = __syncthreads_or(anyCross);     // wall crossings are rare: skip 12 reductions otherwise
         for (int k = 0; k < 6; k++)
@@ -268,48 +285,63 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: exclusive prefix sum of the cell histogram (calc_firstAtomInCell cuSort.cu:130-143: 1 thread there)
-//     one 1024-thread workgroup; each thread owns a contiguous run of cells.
+// K4: exclusive prefix sum of the cell histogram (calc_firstAtomInCell cuSort.cu:130-143 is ONE thread).
+//   k_scan_totals : each workgroup sums its chunk of kScanChunk cells
+//   k_scan_apply  : offset = sum of the preceding chunk totals, then a local exclusive scan
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_cells(int nCell, const int32_t* __restrict__ cellCount, int32_t* __restrict__ cellStart,
-                                                     StepParams P, Counts* cnt, int slabMode)
+constexpr int kScanChunk = 1024;    // cells per workgroup (4 per thread)
+
+__global__ __launch_bounds__(kBlock) void k_scan_totals(int nCell, const int32_t* __restrict__ cellCount, int32_t* __restrict__ chunkTot)
 {
-    __shared__ int waveTot[16];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int per = (nCell + 1023) / 1024;
-    const int b = tid * per, e = min(b + per, nCell);
+    __shared__ int wt[kBlock / kWave];
+    const int c0 = blockIdx.x * kScanChunk + threadIdx.x * 4;
     int s = 0;
-    for (int c = b; c < e; c++) s += cellCount[c];
-    // inclusive scan of per-thread totals across the wave, then across waves
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (c0 + k < nCell) s += cellCount[c0 + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, kWave);
+    if ((threadIdx.x & 63) == 0) wt[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) chunkTot[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_apply(int nCell, const int32_t* __restrict__ cellCount, const int32_t* __restrict__ chunkTot,
+                                                       int32_t* __restrict__ cellStart, Counts* cnt)
+{
+    __shared__ int wt[kBlock / kWave];
+    __shared__ int chunkBase;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // sum of all preceding chunk totals
+    int pre = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += kBlock) pre += chunkTot[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_down(pre, o, kWave);
+    if (lane == 0) wt[w] = pre;
+    __syncthreads();
+    if (tid == 0) chunkBase = wt[0] + wt[1] + wt[2] + wt[3];
+    __syncthreads();
+    const int c0 = blockIdx.x * kScanChunk + tid * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = (c0 + k < nCell) ? cellCount[c0 + k] : 0; s += v[k]; }
     int incl = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, kWave); if (lane >= o) incl += n; }
-    if (lane == 63) waveTot[w] = incl;
     __syncthreads();
-    int base = 0;
-    for (int k = 0; k < w; k++) base += waveTot[k];
-    int run = base + incl - s;
-    for (int c = b; c < e; c++) { cellStart[c] = run; run += cellCount[c]; }
-    if (tid == 1023)
-    {
-        int total = base + incl;
-        cellStart[nCell] = total;
-        cnt->nTotal = total;
-    }
+    if (lane == 63) wt[w] = incl;
     __syncthreads();
-    if (tid == 0)
+    int run = chunkBase + incl - s;
+    for (int k = 0; k < w; k++) run += wt[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (c0 + k < nCell) cellStart[c0 + k] = run; run += v[k]; }
+    if (blockIdx.x == gridDim.x - 1 && tid == kBlock - 1)
     {
+        cellStart[nCell] = run;           // total number of resident atoms
+        cnt->nTotal = run;
         // the atoms to be sorted are the old owned range plus whatever k_unpack appended behind it
         cnt->srcBegin = cnt->ownedBegin;
         cnt->srcEnd = cnt->ownedEnd + cnt->nRecv;
         cnt->nRecv = 0;
-        if (slabMode)
-        {   // owned atoms = cells of the x-layers [hw, ncxLocal - hw): a contiguous range of the sorted arrays
-            const int plane = P.nc[1] * P.nc[2];
-            cnt->ownedBegin = cellStart[P.hw[0] * plane];
-            cnt->ownedEnd = cellStart[(P.ncxLocal - P.hw[0]) * plane];
-        }
-        else { cnt->ownedBegin = 0; cnt->ownedEnd = cellStart[nCell]; }
     }
 }
 
@@ -336,9 +368,19 @@ __global__ __launch_bounds__(kBlock) void k_place(const Counts* __restrict__ cnt
 __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict__ cnt, const int32_t* __restrict__ cellStart,
                                                         const int32_t* __restrict__ tmpId, const int32_t* __restrict__ tmpSrc,
                                                         const int32_t* __restrict__ tmpCell, AtomArrays src, AtomArrays dst,
-                                                        int32_t* __restrict__ cellOfSorted, int carryForces)
+                                                        int32_t* __restrict__ cellOfSorted, int carryForces, StepParams P, Counts* cntOut)
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p == 0)
+    {   // new owned range (nobody in this launch reads it): the cells of the x-layers [hw, ncxLocal - hw) on a slab rank
+        if (P.nranks > 1)
+        {
+            const int plane = P.nc[1] * P.nc[2];
+            cntOut->ownedBegin = cellStart[P.hw[0] * plane];
+            cntOut->ownedEnd = cellStart[(P.ncxLocal - P.hw[0]) * plane];
+        }
+        else { cntOut->ownedBegin = 0; cntOut->ownedEnd = cnt->nTotal; }
+    }
     if (p >= cnt->nTotal) return;
     const int c = tmpCell[p];
     const int s = cellStart[c], e = cellStart[c + 1];
@@ -574,14 +616,11 @@ __global__ __launch_bounds__(1024) void k_collect(const double* __restrict__ par
                                                   DevStats* st, unsigned slotMask)
 {
     __shared__ double scratch[16];
-    for (int slot = 0; slot < PS_COUNT; slot++)
-    {
-        if (!((slotMask >> slot) & 1u)) continue;
-        const int nb = (slot == PS_EVDW || slot == PS_ECOUL || slot == PS_DROPPED) ? nBlocksPair : nBlocksAtoms;
-        double v = reduce_slot(partials, maxBlocks, nb, slot, scratch);
-        if (threadIdx.x == 0) st->local[slot] = v;
-        __syncthreads();
-    }
+    const int slot = blockIdx.x;                      // one workgroup per reduction slot
+    if (!((slotMask >> slot) & 1u)) return;
+    const int nb = (slot == PS_EVDW || slot == PS_ECOUL || slot == PS_DROPPED) ? nBlocksPair : nBlocksAtoms;
+    double v = reduce_slot(partials, maxBlocks, nb, slot, scratch);
+    if (threadIdx.x == 0) st->local[slot] = v;
 }
 
 // reset_quantities + calc_quantities (cuMDfunc.cu:270, main.cu:121-194 ; serial calc_chars integrators.cpp:63-73).

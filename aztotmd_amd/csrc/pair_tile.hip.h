@@ -1,9 +1,245 @@
-// LDS-tiled pair kernel (variant 2) - placeholder until the tiled kernel lands.
+// Pair-force kernel, variant 2: one wave64 per cell, neighbour atoms staged through LDS.
+//
+// Replaces the reference's cell_list5a + cell_list4b_noshared + pair_1 (cuPairs.cu:2266,1474,117), which walk
+// host-built O(nCell^2) cell-pair tables, re-read both atoms from global memory for every pair and add every
+// pair force with three global float atomics.  Here:
+//   * the neighbour stencil (2hw+1)^3 is walked on the fly; the periodic image shift is applied once per
+//     neighbour run while it is staged, so the inner loop has no minimum-image selects;
+//   * staging is a coalesced SoA load of whole z-runs (cells that are contiguous in the sorted arrays), pruned
+//     against the centre cell's bounding box and packed into LDS with wave ballot + popcount prefix;
+//   * lanes are split (i-slot, j-slice): 16 atoms x 4 slices for the typical 13-atom cell, so ~85 % of the lanes
+//     work instead of 21 %; slices are folded with two xor-shuffles in a fixed order;
+//   * every atom's force is the sum over ALL its neighbours (no Newton-3 halving): written once, no atomics,
+//     bit-reproducible; each pair visit books half of the pair energy;
+//   * workgroup -> cell mapping keeps each XCD on a contiguous eighth of the cell list (private L2 per XCD).
+// No MFMA: the work is distance tests and scalar-potential evaluations, not a contraction.
 #pragma once
 #include "kernels.hip.h"
 
 namespace aztot {
-inline bool pair_tile_supported(const StepParams&) { return false; }
-inline int pair_tile_grid(const StepParams&) { return 0; }
-inline void launch_pair_tile(const StepParams&, const SpecTable&, const DevPot*, AtomArrays, const Counts*, const int32_t*, double*, int, hipStream_t) {}
+
+constexpr int kTileCap = 320;      // candidates resident in LDS per wave (10 KB fp64 xyz + index/type)
+
+// the tile kernel needs every neighbour cell to be reached through exactly one periodic image
+inline bool pair_tile_supported(const StepParams& P)
+{
+    for (int k = 0; k < 3; k++)
+    {
+        const bool slabX = (k == 0 && P.nranks > 1);
+        if (!slabX && P.nc[k] < 2 * P.hw[k] + 1) return false;
+    }
+    return true;
+}
+
+inline int pair_tile_cells(const StepParams& P)
+{
+    const int plane = P.nc[1] * P.nc[2];
+    return (P.nranks > 1) ? (P.ncxLocal - 2 * P.hw[0]) * plane : P.nCellLocal;
+}
+inline int pair_tile_grid(const StepParams& P) { return 8 * ((pair_tile_cells(P) + 7) / 8); }
+
+template <int MODE>   // 0: generic (species table, Coulomb, radii) ; 1: one species, Lennard-Jones only
+__global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
+                                                     const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
+                                                     double* __restrict__ partials, int maxBlocks)
+{
+    __shared__ double tx[kTileCap], ty[kTileCap], tz[kTileCap];
+    __shared__ int32_t tidx[kTileCap];
+    __shared__ int32_t ttyp[MODE == 0 ? kTileCap : 1];
+    __shared__ double trad[MODE == 0 ? kTileCap : 1];
+
+    const int lane = threadIdx.x;
+    // XCD-aware mapping: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous run of cells
+    const int per = (nCellsRun + 7) >> 3;
+    const int cr = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    PairAcc acc = {0, 0, 0, 0, 0, 0};
+    double eV = 0.0, eC = 0.0, dropped = 0.0;
+    if (cr < nCellsRun)
+    {
+        const int cell = firstCell + cr;
+        const int ncy = P.nc[1], ncz = P.nc[2];
+        const int cz = cell % ncz, cy = (cell / ncz) % ncy, lx = cell / (ncy * ncz);
+        const int ib = cellStart[cell], ie = cellStart[cell + 1];
+        // bounding box of the centre cell (global coordinates)
+        const double lo0 = (lx + P.cx0) * P.csz[0], lo1 = cy * P.csz[1], lo2 = cz * P.csz[2];
+        const double hi0 = lo0 + P.csz[0], hi1 = lo1 + P.csz[1], hi2 = lo2 + P.csz[2];
+        const DevPot lj = pots[0];
+        for (int i0 = ib; i0 < ie; i0 += kWave)
+        {
+            const int nthis = min(kWave, ie - i0);
+            const int lg = nthis <= 16 ? 4 : (nthis <= 32 ? 5 : 6);     // log2(i-slots)
+            const int islots = 1 << lg, nslice = kWave >> lg;
+            const int il = lane & (islots - 1), slice = lane >> lg;
+            const bool validI = il < nthis;
+            const int myi = i0 + il;
+            double xi = 1e30, yi = 1e30, zi = 1e30, radi = 0.0;
+            int ti = 0;
+            if (validI)
+            {
+                xi = A.x[myi]; yi = A.y[myi]; zi = A.z[myi];
+                if (MODE == 0) { ti = A.type[myi]; if (P.use_radii) radi = A.rad[myi]; }
+            }
+            acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0; acc.eV = 0.0; acc.eC = 0.0; acc.dropped = 0.0;
+            int T = 0;
+
+            // one LDS chunk = two passes per round of 96 candidates per lane:
+            //   pass 1  distance tests only (7 fp64 ops per candidate); hits are recorded in per-lane bit masks
+            //   pass 2  every lane pops its own hits, so the expensive potential runs on densely filled waves
+            //           (about 20 % of the candidates are inside the cut-off: evaluating the potential inline would
+            //            execute it for nearly every wave-iteration with 80 % of the lanes masked off)
+            auto process = [&]() {
+                __builtin_amdgcn_wave_barrier();
+                const int iters = (P.pad0 & 1) ? 0 : (T + nslice - 1) / nslice;      // pad0: ablation switches (bench only)
+                for (int rb = 0; rb < iters; rb += 96)
+                {
+                    uint32_t m[3] = {0u, 0u, 0u};
+#pragma unroll
+                    for (int w = 0; w < 3; w++)
+                    {
+                        const int kb = rb + w * 32;
+                        const int nb = min(32, iters - kb);
+                        uint32_t mm = 0u;
+#pragma unroll 4
+                        for (int b = 0; b < nb; b++)
+                        {
+                            const int k = (kb + b) * nslice + slice;
+                            const int kc = min(k, T - 1);
+                            const double dx = xi - tx[kc], dy = yi - ty[kc], dz = zi - tz[kc];
+                            const double r2 = dx * dx + dy * dy + dz * dz;
+                            mm |= (uint32_t)((k < T) & (r2 <= P.r2Max)) << b;
+                        }
+                        m[w] = mm;
+                    }
+                    if (P.pad0 & 2) { acc.fx += (double)(m[0] ^ m[1] ^ m[2]); m[0] = m[1] = m[2] = 0u; }
+                    while (__any((m[0] | m[1] | m[2]) != 0u))
+                    {
+                        int kk = -1;
+                        if (m[0]) { kk = __ffs(m[0]) - 1; m[0] &= m[0] - 1u; }
+                        else if (m[1]) { kk = 32 + __ffs(m[1]) - 1; m[1] &= m[1] - 1u; }
+                        else if (m[2]) { kk = 64 + __ffs(m[2]) - 1; m[2] &= m[2] - 1u; }
+                        if (kk >= 0)
+                        {
+                            const int k = (rb + kk) * nslice + slice;
+                            if (tidx[k] != myi)
+                            {
+                                const double dx = xi - tx[k], dy = yi - ty[k], dz = zi - tz[k];
+                                const double r2 = dx * dx + dy * dy + dz * dz;
+                                if (MODE == 1)
+                                {   // fer_lj vdw.cpp:16-26 ; pair_inter integrators.cpp:139-185
+                                    if (r2 <= lj.r2cut)
+                                    {
+                                        const double r2i = 1.0 / r2;
+                                        const double sr2 = lj.p1 * r2i;
+                                        const double sr6 = sr2 * sr2 * sr2;
+                                        acc.eV += 0.5 * (lj.p0 * sr6 * (sr6 - 1.0));
+                                        const double f = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
+                                        if (f * f > 1e10) acc.dropped += 0.5;
+                                        else { acc.fx += f * dx; acc.fy += f * dy; acc.fz += f * dz; }
+                                    }
+                                }
+                                else
+                                    pair_visit(P, S, pots, dx, dy, dz, r2, ti, ttyp[k], radi, trad[k], acc);
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                T = 0;
+            };
+
+            // walk the stencil: for every (x, y) neighbour column the z-neighbours form at most three contiguous runs
+            for (int ox = 0; ox < P.nOff[0]; ox++)
+            {
+                int nx = lx + ox - P.hw[0];
+                double shx = 0.0;
+                if (P.nranks > 1)
+                {   // slab window: ghost layers are resident; their coordinates are global, so shift across the seam
+                    const int gx = nx + P.cx0;
+                    if (gx < 0) shx = -P.L[0]; else if (gx >= P.nc[0]) shx = P.L[0];
+                }
+                else if (nx < 0) { nx += P.nc[0]; shx = -P.L[0]; }
+                else if (nx >= P.nc[0]) { nx -= P.nc[0]; shx = P.L[0]; }
+                for (int oy = 0; oy < P.nOff[1]; oy++)
+                {
+                    int ny = cy + oy - P.hw[1];
+                    double shy = 0.0;
+                    if (ny < 0) { ny += ncy; shy = -P.L[1]; } else if (ny >= ncy) { ny -= ncy; shy = P.L[1]; }
+                    const int colBase = (nx * ncy + ny) * ncz;
+                    const int zlo = cz - P.hw[2], zhi = cz + P.hw[2];
+                    for (int seg = 0; seg < 3; seg++)
+                    {
+                        int zs, ze; double shz;
+                        if (seg == 0) { zs = max(zlo, 0); ze = min(zhi, ncz - 1); shz = 0.0; }
+                        else if (seg == 1) { if (zlo >= 0) continue; zs = zlo + ncz; ze = ncz - 1; shz = -P.L[2]; }
+                        else { if (zhi < ncz) continue; zs = 0; ze = zhi - ncz; shz = P.L[2]; }
+                        const int jb = cellStart[colBase + zs], je = cellStart[colBase + ze + 1];
+                        for (int j0 = jb; j0 < je; j0 += kWave)
+                        {
+                            if (T + kWave > kTileCap) process();
+                            const int j = j0 + lane;
+                            bool keep = false;
+                            double xj = 0, yj = 0, zj = 0;
+                            if (j < je)
+                            {
+                                xj = A.x[j] + shx; yj = A.y[j] + shy; zj = A.z[j] + shz;
+                                // distance from the centre cell's box: atoms farther than the cut-off cannot reach any atom in it
+                                const double bx = fmax(fmax(lo0 - xj, xj - hi0), 0.0);
+                                const double by = fmax(fmax(lo1 - yj, yj - hi1), 0.0);
+                                const double bz = fmax(fmax(lo2 - zj, zj - hi2), 0.0);
+                                keep = (bx * bx + by * by + bz * bz) <= P.r2Max;
+                            }
+                            const unsigned long long mask = __ballot(keep);
+                            if (keep)
+                            {
+                                const int p = T + __popcll(mask & ((1ULL << lane) - 1ULL));
+                                tx[p] = xj; ty[p] = yj; tz[p] = zj; tidx[p] = j;
+                                if (MODE == 0) { ttyp[p] = A.type[j]; trad[p] = P.use_radii ? A.rad[j] : 0.0; }
+                            }
+                            T += __popcll(mask);
+                        }
+                    }
+                }
+            }
+            process();
+
+            // fold the j-slices (fixed order) and write the force: clear_force + pair sums
+            for (int o = kWave >> 1; o >= islots; o >>= 1)
+            {
+                acc.fx += __shfl_xor(acc.fx, o, kWave);
+                acc.fy += __shfl_xor(acc.fy, o, kWave);
+                acc.fz += __shfl_xor(acc.fz, o, kWave);
+            }
+            if (validI && slice == 0)
+            {
+                double q = 0.0;
+                if (MODE == 0) q = S.charge[ti];
+                A.fx[myi] = -q * P.E[0] + acc.fx;          // clear_force integrators.cpp:17-39
+                A.fy[myi] = -q * P.E[1] + acc.fy;
+                A.fz[myi] = -q * P.E[2] + acc.fz;
+            }
+            eV += acc.eV; eC += acc.eC; dropped += acc.dropped;
+        }
+    }
+    eV = wave_sum(eV); eC = wave_sum(eC); dropped = wave_sum(dropped);
+    if (lane == 0)
+    {
+        put_partial(partials, maxBlocks, PS_EVDW, eV);
+        put_partial(partials, maxBlocks, PS_ECOUL, eC);
+        put_partial(partials, maxBlocks, PS_DROPPED, dropped);
+    }
+}
+
+inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts*, const int32_t* cellStart,
+                             double* partials, int maxBlocks, hipStream_t stream)
+{
+    const int nRun = pair_tile_cells(P);
+    const int plane = P.nc[1] * P.nc[2];
+    const int first = (P.nranks > 1) ? P.hw[0] * plane : 0;
+    const int grid = pair_tile_grid(P);
+    if (P.single_lj)
+        hipLaunchKernelGGL(k_pair_tile<1>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
+    else
+        hipLaunchKernelGGL(k_pair_tile<0>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
+}
+
 }  // namespace aztot

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py - ns/day of the azTotMD per-step hot path on MI355X (see DESIGN.md "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json config "1 000 000 Ar LJ", SURVEY 8d "C4"): 1 000 188 argon atoms, FCC 63^3 cells of
+5.735 A with +-0.15 A jitter (seed 20240502), LJ eps 0.01006 eV sigma 3.3952 A, cut-off 8.5 A, dt 1 fs, NVE,
+fp64.  With N GPUs the SAME box is split into N slabs along x (strong scaling), one process per GPU, ghost
+atoms exchanged with the two ring neighbours over RCCL.
+
+A "step" is one pass of the hot path (half-kick+drift+wrap+bin, scan, sort, pair forces, half-kick, energy
+bookkeeping) over all atoms.  Atoms are resident in HBM when the timed region starts.
+
+Output: ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12            # B/s, MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+PAIR_BYTES_PER_ATOM = 52.0   # x,y,z,type read + fx,fy,fz written
+PAIR_BYTES_PER_CELL = 8.0    # cellStart/cellCount
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C4", help="C4 (1 000 188 Ar LJ, default), C3 (+Fennell Coulomb), C2 (40 000 Ar LJ)")
+    ap.add_argument("--pair-variant", type=int, default=0)
+    ap.add_argument("--cell-size", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline sample (0: sized for ~15 s)")
+    ap.add_argument("--debug", type=int, default=0, help="kernel ablation switches (results invalid)")
+    ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels (enables hipGraph replay)")
+    return ap.parse_args()
+
+
+def cpu_baseline(case, steps):
+    """The reference's own serial code (oracle/_ref, built from /root/reference) when the binary travelled here,
+    else our C port of it (oracle/liboracle.so); one thread, as the reference is serial (main.cpp, no OpenMP)."""
+    from oracle import oracle
+    import numpy as np
+    n = len(case["types"])
+    dt = case["dt"]
+    if oracle.ref_available():
+        c = dict(case)
+        c.update(nsteps=steps, dump=[], init_forces=0, use_clist=1, center_box=0)
+        drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+        from oracle import casefile
+        with tempfile.TemporaryDirectory() as td:
+            cp, op = os.path.join(td, "case.bin"), os.path.join(td, "out.bin")
+            casefile.write_case(cp, c)
+            r = subprocess.run([drv, cp, op], capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                raise RuntimeError("ref_driver failed: " + r.stderr[-500:])
+            summ = json.loads(r.stdout.strip().splitlines()[-1])
+        wall = summ["wall_s"]
+        kind = "reference"
+    else:
+        o = oracle.Oracle(case)
+        o.forces(1)
+        t0 = time.perf_counter()
+        o.step(steps)
+        wall = time.perf_counter() - t0
+        kind = "port"
+    nsday = steps * dt * 1e-3 / wall * 86400.0
+    return {"value": nsday, "unit": "ns/day", "cores": 1, "kind": kind,
+            "sample": "%d steps of the same %d-atom workload, linked-cell serial path, 1 thread; %.2f s wall; %.3f Matom-steps/s"
+                      % (steps, n, wall, n * steps / wall / 1e6),
+            "host_cpu": _cpu_model(), "host_cores": os.cpu_count()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    import numpy as np
+    import torch
+    from aztotmd_amd import api, inputs
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only; data path = RCCL in libaztot
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    case = inputs.config(a.workload)
+    n_atoms = len(case["types"])
+    model = api.Model.from_case(case)
+    slab = None
+    if world > 1:
+        idb = [api.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(idb, src=0)
+        slab = {"rank": rank, "nranks": world, "rccl_id": idb[0]}
+    profile = 0 if a.no_profile else 1
+    eng = api.Engine(model, device=local_rank, initial_forces=1, pair_variant=a.pair_variant, cell_size=a.cell_size,
+                     use_graph=1, profile=profile, slab=slab, debug=a.debug)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    eng.step(a.warmup)
+    if profile:
+        eng.reset_kernel_times()
+    barrier()
+    t0 = time.perf_counter()
+    eng.step(a.steps)             # returns after the engine's stream has drained
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    st = eng.stats()
+    ktimes = eng.kernel_times() if profile else {}
+    if dist is not None and profile:
+        # slowest rank per kernel
+        names = sorted(ktimes)
+        t = torch.tensor([ktimes[k]["ms"] / max(ktimes[k]["calls"], 1) for k in names], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        for k, v in zip(names, t.tolist()):
+            ktimes[k]["avg_ms_max_over_ranks"] = v
+
+    if rank == 0:
+        dt_ps = case["dt"]
+        ms_per_step = wall / a.steps * 1e3
+        nsday = a.steps * dt_ps * 1e-3 / wall * 86400.0
+        out = {
+            "metric": "ns_per_day", "value": nsday, "unit": "ns/day", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": {"C4": "1 000 188 Ar, LJ rc 8.5 A, FCC 63^3 a=5.735 jitter 0.15, dt 1 fs, NVE (BASELINE config '1 000 000 Ar LJ', SURVEY C4)",
+                                    "C3": "1 000 188 atoms, LJ rc 8.5 A + Fennell/DSF Coulomb q=+-0.2 (SURVEY C3)",
+                                    "C2": "40 000 Ar, LJ rc 8.5 A (SURVEY C2)"}.get(a.workload, a.workload),
+                       "n_atoms": n_atoms, "n_cells": st["n_cells"], "decomposition": "single GPU" if world == 1 else "%d slabs along x, RCCL halo" % world,
+                       "pair_variant": a.pair_variant, "per_kernel_hip_events": bool(profile)},
+            "matom_steps_per_s": n_atoms * a.steps / wall / 1e6,
+            "energy": {"engTot": st["engTot"], "engVdW": st["engVdW"], "engKin": st["engKin"], "pairs_dropped": st["pairs_dropped"]},
+        }
+        if ktimes:
+            kern = {k: {"avg_us": 1e3 * v.get("avg_ms_max_over_ranks", v["ms"] / max(v["calls"], 1)), "calls": v["calls"]} for k, v in ktimes.items()}
+            out["kernels"] = kern
+            pair_name = max((k for k in kern if k.startswith("pair")), key=lambda k: kern[k]["avg_us"], default=None)
+            if pair_name:
+                t_pair = kern[pair_name]["avg_us"] * 1e-6
+                alg = PAIR_BYTES_PER_ATOM * n_atoms / world + PAIR_BYTES_PER_CELL * st["n_cells"] / world
+                traffic = None
+                tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if os.path.exists(tp):
+                    try:
+                        rec = json.load(open(tp)).get("%s:%s:%d" % (a.workload, pair_name, world))
+                        traffic = rec["hbm_bytes_per_launch"] if rec else None
+                    except Exception:
+                        traffic = None
+                out["roofline"] = {"bound": "hbm", "kernel": pair_name, "achieved": alg / t_pair / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                   "frac": alg / t_pair / HBM_PEAK, "traffic": traffic,
+                                   "algorithmic_bytes_per_launch": alg, "avg_launch_us": t_pair * 1e6,
+                                   "note": "fp64 pair kernel is FP64-ALU/LDS bound (about 100 FLOP per compulsory byte): see DESIGN.md"}
+        if world == 1 and not a.no_cpu_baseline:
+            steps_cpu = a.cpu_steps or max(2, int(round(5.0e6 / n_atoms * 1.0)))   # ~3 us per atom-step -> about 15 s
+            steps_cpu = min(steps_cpu, 200)
+            try:
+                out["cpu_baseline"] = cpu_baseline(case, steps_cpu)
+            except Exception as ex:   # noqa: BLE001 - the baseline is reported, never required for the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "ns/day", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
