@@ -18,7 +18,9 @@
 
 namespace aztot {
 
-constexpr int kTileCap = 320;      // candidates resident in LDS per wave (10 KB fp64 xyz + index/type)
+constexpr int kTileCap = 320;      // candidates resident in LDS per wave
+constexpr int kTilePad = 16;       // far-away dummies behind the last candidate (4 unrolled iterations x 4 slices)
+constexpr int kTileLds = kTileCap + kTilePad;
 
 // the tile kernel needs every neighbour cell to be reached through exactly one periodic image
 inline bool pair_tile_supported(const StepParams& P)
@@ -38,15 +40,106 @@ inline int pair_tile_cells(const StepParams& P)
 }
 inline int pair_tile_grid(const StepParams& P) { return 8 * ((pair_tile_cells(P) + 7) / 8); }
 
+// 1/x: v_rcp_f64 (about 2^-24 relative) refined by two Newton steps -> error within ~1 ulp; 5 instructions instead
+// of the 11 of the IEEE division sequence.  x is a squared distance inside the cut-off: normal, positive.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+
+// The two passes over one staged chunk; LG = log2(i-slots), NS = 64 >> LG = lanes (slices) per i-atom.
+//   pass 1  distance tests only (7 fp64 ops per candidate); hits are recorded in three per-lane 32-bit masks
+//   pass 2  every lane pops its own hits (from whichever word still has one), so the potential runs on densely
+//           filled waves: only ~20 % of the candidates are inside the cut-off, and evaluating inline would execute
+//           the potential on nearly every wave-iteration with 80 % of the lanes masked off.
+// rocprof shows the kernel VALU-issue bound (VALU busy ~85 %), so this is all about instructions per wave: constant
+// LDS offsets (NS is a template parameter), no bounds clamps (far-away dummies pad the tile), Newton-refined
+// v_rcp_f64, branch-free potential.
+template <int MODE, int LG>
+__device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots, const DevPot& lj,
+                                            const double* tx, const double* ty, const double* tz, const int32_t* ttyp, const double* trad,
+                                            int T, int slice, double xi, double yi, double zi, int ti, double radi, PairAcc& acc)
+{
+    constexpr int NS = kWave >> LG;
+    const int iters = ((T + NS - 1) / NS + 3) & ~3;        // per-lane candidates, rounded up to the unroll factor
+    for (int rb = 0; rb < iters; rb += 96)
+    {
+        uint32_t m[3];
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+        {
+            const int tb = rb + w * 32;
+            const int nb = min(32, iters - tb);            // multiple of 4, may be <= 0
+            uint32_t mm = 0u;
+            const double* px = &tx[tb * NS + slice];
+            const double* py = &ty[tb * NS + slice];
+            const double* pz = &tz[tb * NS + slice];
+            for (int b = 0; b < nb; b += 4)
+            {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    const double dx = xi - px[u * NS], dy = yi - py[u * NS], dz = zi - pz[u * NS];
+                    const double r2 = dx * dx + dy * dy + dz * dz;
+                    mm = (mm << 1) | (uint32_t)(r2 <= P.r2Max);      // newest candidate in bit 0
+                }
+                px += 4 * NS; py += 4 * NS; pz += 4 * NS;
+            }
+            // left-align: candidate number b of this word sits at bit 31 - b, whatever the word length
+            m[w] = (nb > 0) ? (mm << (32 - nb)) : 0u;
+        }
+        if (P.pad0 & 2) { acc.fx += (double)(m[0] ^ m[1] ^ m[2]); m[0] = m[1] = m[2] = 0u; }
+        const int k0 = rb * NS + slice;
+        while (__any((m[0] | m[1] | m[2]) != 0u))
+        {
+            // pop the first remaining hit of this lane: word selection by two compares, then one clz.  The body is
+            // branch-free (lanes without a hit run on a dummy candidate and are masked out at the end): a conditional
+            // body makes the compiler shuffle all accumulators through copies on every iteration.
+            const bool h0 = m[0] != 0u, h1 = m[1] != 0u;
+            const uint32_t mw = h0 ? m[0] : (h1 ? m[1] : m[2]);
+            const bool live = mw != 0u;
+            const int b = __clz(mw | 1u);
+            const uint32_t bit = live ? (0x80000000u >> b) : 0u;
+            const int woff = h0 ? 0 : (h1 ? 32 * NS : 64 * NS);
+            m[0] ^= h0 ? bit : 0u;
+            m[1] ^= (!h0 & h1) ? bit : 0u;
+            m[2] ^= (!h0 & !h1) ? bit : 0u;
+            const int k = live ? (k0 + woff + b * NS) : k0;
+            const double dx = xi - tx[k], dy = yi - ty[k], dz = zi - tz[k];
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            if (MODE == 1)
+            {   // fer_lj vdw.cpp:16-26 ; pair_inter integrators.cpp:139-185.  The atom itself (r2 == 0 exactly: its own
+                // cell is part of the tile, unshifted) and pairs beyond the potential's own cut-off are masked out at the
+                // end; 1/0 = inf only ever meets a select.
+                const double r2i = fast_rcp(r2);
+                const double sr2 = lj.p1 * r2i;
+                const double sr6 = sr2 * sr2 * sr2;
+                const double e = lj.p0 * sr6 * (sr6 - 1.0);
+                const double f = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
+                const bool pairOk = live & (r2 > 0.0) & (r2 <= lj.r2cut);
+                const bool forceOk = pairOk & !(f * f > 1e10);           // integrators.cpp:170-174
+                const double fm = forceOk ? f : 0.0;
+                acc.eV += pairOk ? 0.5 * e : 0.0;
+                acc.dropped += (pairOk & !forceOk) ? 0.5 : 0.0;
+                acc.fx += fm * dx; acc.fy += fm * dy; acc.fz += fm * dz;
+            }
+            else if (live && r2 > 0.0)
+                pair_visit(P, S, pots, dx, dy, dz, r2, ti, ttyp[k], radi, trad[k], acc);
+        }
+    }
+}
+
 template <int MODE>   // 0: generic (species table, Coulomb, radii) ; 1: one species, Lennard-Jones only
 __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks)
 {
-    __shared__ double tx[kTileCap], ty[kTileCap], tz[kTileCap];
-    __shared__ int32_t tidx[kTileCap];
-    __shared__ int32_t ttyp[MODE == 0 ? kTileCap : 1];
-    __shared__ double trad[MODE == 0 ? kTileCap : 1];
+    __shared__ double tx[kTileLds], ty[kTileLds], tz[kTileLds];
+    __shared__ int32_t ttyp[MODE == 0 ? kTileLds : 1];
+    __shared__ double trad[MODE == 0 ? kTileLds : 1];
 
     const int lane = threadIdx.x;
     // XCD-aware mapping: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous run of cells
@@ -68,7 +161,7 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
         {
             const int nthis = min(kWave, ie - i0);
             const int lg = nthis <= 16 ? 4 : (nthis <= 32 ? 5 : 6);     // log2(i-slots)
-            const int islots = 1 << lg, nslice = kWave >> lg;
+            const int islots = 1 << lg;
             const int il = lane & (islots - 1), slice = lane >> lg;
             const bool validI = il < nthis;
             const int myi = i0 + il;
@@ -88,60 +181,13 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
             //           (about 20 % of the candidates are inside the cut-off: evaluating the potential inline would
             //            execute it for nearly every wave-iteration with 80 % of the lanes masked off)
             auto process = [&]() {
+                if (lane < kTilePad) tx[T + lane] = -1e30;       // far-away dummies: the passes need no bounds checks
                 __builtin_amdgcn_wave_barrier();
-                const int iters = (P.pad0 & 1) ? 0 : (T + nslice - 1) / nslice;      // pad0: ablation switches (bench only)
-                for (int rb = 0; rb < iters; rb += 96)
+                if (!(P.pad0 & 1))
                 {
-                    uint32_t m[3] = {0u, 0u, 0u};
-#pragma unroll
-                    for (int w = 0; w < 3; w++)
-                    {
-                        const int kb = rb + w * 32;
-                        const int nb = min(32, iters - kb);
-                        uint32_t mm = 0u;
-#pragma unroll 4
-                        for (int b = 0; b < nb; b++)
-                        {
-                            const int k = (kb + b) * nslice + slice;
-                            const int kc = min(k, T - 1);
-                            const double dx = xi - tx[kc], dy = yi - ty[kc], dz = zi - tz[kc];
-                            const double r2 = dx * dx + dy * dy + dz * dz;
-                            mm |= (uint32_t)((k < T) & (r2 <= P.r2Max)) << b;
-                        }
-                        m[w] = mm;
-                    }
-                    if (P.pad0 & 2) { acc.fx += (double)(m[0] ^ m[1] ^ m[2]); m[0] = m[1] = m[2] = 0u; }
-                    while (__any((m[0] | m[1] | m[2]) != 0u))
-                    {
-                        int kk = -1;
-                        if (m[0]) { kk = __ffs(m[0]) - 1; m[0] &= m[0] - 1u; }
-                        else if (m[1]) { kk = 32 + __ffs(m[1]) - 1; m[1] &= m[1] - 1u; }
-                        else if (m[2]) { kk = 64 + __ffs(m[2]) - 1; m[2] &= m[2] - 1u; }
-                        if (kk >= 0)
-                        {
-                            const int k = (rb + kk) * nslice + slice;
-                            if (tidx[k] != myi)
-                            {
-                                const double dx = xi - tx[k], dy = yi - ty[k], dz = zi - tz[k];
-                                const double r2 = dx * dx + dy * dy + dz * dz;
-                                if (MODE == 1)
-                                {   // fer_lj vdw.cpp:16-26 ; pair_inter integrators.cpp:139-185
-                                    if (r2 <= lj.r2cut)
-                                    {
-                                        const double r2i = 1.0 / r2;
-                                        const double sr2 = lj.p1 * r2i;
-                                        const double sr6 = sr2 * sr2 * sr2;
-                                        acc.eV += 0.5 * (lj.p0 * sr6 * (sr6 - 1.0));
-                                        const double f = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
-                                        if (f * f > 1e10) acc.dropped += 0.5;
-                                        else { acc.fx += f * dx; acc.fy += f * dy; acc.fz += f * dz; }
-                                    }
-                                }
-                                else
-                                    pair_visit(P, S, pots, dx, dy, dz, r2, ti, ttyp[k], radi, trad[k], acc);
-                            }
-                        }
-                    }
+                    if (lg == 4) tile_passes<MODE, 4>(P, S, pots, lj, tx, ty, tz, ttyp, trad, T, slice, xi, yi, zi, ti, radi, acc);
+                    else if (lg == 5) tile_passes<MODE, 5>(P, S, pots, lj, tx, ty, tz, ttyp, trad, T, slice, xi, yi, zi, ti, radi, acc);
+                    else tile_passes<MODE, 6>(P, S, pots, lj, tx, ty, tz, ttyp, trad, T, slice, xi, yi, zi, ti, radi, acc);
                 }
                 __builtin_amdgcn_wave_barrier();
                 T = 0;
@@ -192,7 +238,7 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
                             if (keep)
                             {
                                 const int p = T + __popcll(mask & ((1ULL << lane) - 1ULL));
-                                tx[p] = xj; ty[p] = yj; tz[p] = zj; tidx[p] = j;
+                                tx[p] = xj; ty[p] = yj; tz[p] = zj;
                                 if (MODE == 0) { ttyp[p] = A.type[j]; trad[p] = P.use_radii ? A.rad[j] : 0.0; }
                             }
                             T += __popcll(mask);
