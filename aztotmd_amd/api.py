@@ -67,7 +67,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
 
 EXPORTS = ("aztot_init_md", "aztot_model_create", "aztot_model_query", "aztot_free_md", "aztot_default_options",
            "aztot_init_device", "aztot_free_device", "aztot_step", "aztot_forces", "aztot_get_stats", "aztot_md_to_host",
-           "aztot_set_state", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_comm_id_bytes", "aztot_comm_make_id",
+           "aztot_set_state", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id",
            "aztot_init_device_slab", "aztot_last_error", "aztot_version")
 
 
@@ -117,6 +117,7 @@ def lib():
         L.aztot_set_state.argtypes = [C.c_void_p, C.POINTER(_State)]
         L.aztot_kernel_times.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.POINTER(C.c_int64), C.c_int]
         L.aztot_reset_kernel_times.argtypes = [C.c_void_p]
+        L.aztot_set_profile.argtypes = [C.c_void_p, C.c_int]
         L.aztot_comm_make_id.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
@@ -308,6 +309,9 @@ class Engine:
 
     def reset_kernel_times(self):
         _check(lib().aztot_reset_kernel_times(self.h))
+
+    def set_profile(self, on):
+        _check(lib().aztot_set_profile(self.h, int(bool(on))))
 
     def close(self):
         if getattr(self, "h", None):

@@ -250,6 +250,12 @@ int aztot_reset_kernel_times(aztot_md* md)
     return guarded([&] { md->eng->reset_kernel_times(); });
 }
 
+int aztot_set_profile(aztot_md* md, int on)
+{
+    if (!md) return fail(AZTOT_ERR_ARG, "null handle");
+    return guarded([&] { md->eng->set_profile(on != 0); });
+}
+
 int aztot_comm_id_bytes(void) { return RcclExchanger::id_bytes(); }
 int aztot_comm_make_id(void* id_bytes)
 {

@@ -40,6 +40,7 @@ public:
     void set_state(const aztot_state& in);
     int kernel_times(std::vector<KernelTimer>& out);
     void reset_kernel_times();
+    void set_profile(bool on) { sync(); profile_ = on; }
     int n_atoms_global() const { return model_.nAt; }
 
 private:

@@ -153,6 +153,8 @@ int aztot_set_state(aztot_md *md, const aztot_state *in);
    names: NUL-separated list written into `names` (cap bytes); ms / calls: arrays of length >= returned count */
 int aztot_kernel_times(aztot_md *md, char *names, int cap, double *ms, int64_t *calls, int max_kernels);
 int aztot_reset_kernel_times(aztot_md *md);
+/* switch per-kernel HIP-event timing on/off at run time (off: the step may be replayed as a hipGraph) */
+int aztot_set_profile(aztot_md *md, int on);
 
 /* ---- multi-GPU slab decomposition (one process per GPU) ---------------------------------------------- */
 /* size of the opaque RCCL unique id; rank 0 creates it, the launcher broadcasts it (e.g. torch.distributed) */

@@ -1,0 +1,178 @@
+"""CPU tests of the input surface: the product's C++ parser (libaztot.so, no GPU needed) against the independent
+Python restatement in oracle/parse.py, on (a) generated inputs that exercise the grammar quirks of the reference's
+scanner, (b) files written by aztotmd_amd.inputs, (c) the reference's shipped case studies when they are present."""
+import os
+
+import numpy as np
+import pytest
+
+from aztotmd_amd import api, inputs
+from oracle import parse
+
+QUIRKY_FIELD = """// comment words are simply not keywords
+spec 2
+Ar  Ar   39.9   0.0   0.0
+Cl- Cl   35.45  -1.0  0.3
+red-ox 0
+frozensp 1 Cl-
+vdw 3
+Ar  Ar  lnjs 4.0    0.01006 3.3952
+Ar  Cl- buck 6.0    300.0     0.7    12.5
+Cl- Cl- bmhs 7.5    0.25 3.1 2.4 60.0 80.0
+radii 1
+Ar  2.73 4.731 0.2
+Cl- 3.0  2.0   6.0
+
+vdw 1
+Ar Ar lnjs 9.9 9.9 9.9
+"""
+QUIRKY_CONTROL = """timestep 0.002 ps
+nstep 1234
+nequil  40
+eqfreq 10
+temperature 298.0\tradi\t0.2
+// nose 0.2
+init_vel\tzero\t0.0332
+permittivity  1.0
+cell_list\t85.0
+max_neigh\t185
+elec\tfenn\t8.0\t0.4\t6\t6\t6
+rdf\t14.0   0.02\t50\t500000\tnucl
+eJump\t0\t1.7\tmetr
+Ux\t\t0.0
+stat\t\t200
+"""
+QUIRKY_CUDA = "nstep stat 50\nnstep msdstat 50\nnthread a 16\nnthread b 48\nnstep traj\t10\n"
+
+
+def write_quirky(d):
+    os.makedirs(d, exist_ok=True)
+    open(os.path.join(d, "field.txt"), "w").write(QUIRKY_FIELD)
+    open(os.path.join(d, "control.txt"), "w").write(QUIRKY_CONTROL)
+    open(os.path.join(d, "cuda.txt"), "w").write(QUIRKY_CUDA)
+    with open(os.path.join(d, "atoms.xyz"), "w") as f:
+        f.write("6\n1 40.000000 41.000000 42.000000\n")
+        for i in range(6):
+            f.write("%s\t%f\t%f\t%f\n" % ("Ar" if i % 2 else "Cl-", 1.5 * i + 0.25, 2.0 * i, 39.0 - i))
+
+
+def compare(directory):
+    m = api.Model.from_dir(directory)
+    o = parse.parse_dir(directory)
+    q = m.query
+    assert int(q("n_atoms")[0]) == o["n_atoms"] and list(q("box")) == o["box"]
+    for key, okey in (("dt", "dt"), ("nstep", "nstep"), ("nequil", "nequil"), ("eqfreq", "eqfreq"), ("temperature", "temperature"),
+                      ("tstat_type", "tstat_type"), ("elec_type", "elec_type"), ("r_real", "r_real"), ("alpha", "alpha"),
+                      ("cell_list", "cell_list"), ("use_cell_list", "use_cell_list"), ("stat", "stat"), ("rmax", "rmax"),
+                      ("r2max", "r2max"), ("degfree", "degfree"), ("tkin", "tkin"), ("scale", "scale"), ("scale2", "scale2"),
+                      ("daipi2", "daipi2")):
+        assert q(key)[0] == pytest.approx(o[okey], rel=1e-15, abs=0), key
+    assert list(q("elecfield")) == o["elecfield"]
+    assert [int(v) for v in q("nthread")] == o["nthread"]
+    assert q("kB")[0] == pytest.approx(parse.KB, rel=1e-15) and q("m_scale")[0] == pytest.approx(parse.M_SCALE, rel=1e-15)
+    assert q("fcoul")[0] == pytest.approx(parse.FCOUL, rel=1e-15)
+    sp = q("species").reshape(-1, 10)
+    for row, s in zip(sp, o["species"]):
+        ref = [s["mass_amu"], s["mass"], s["charge"], s["charged"], s["frozen"], s["rMass_hdt"], s["radA"], s["radB"], s["mxEng"], s["number"]]
+        assert row.tolist() == pytest.approx(ref, rel=1e-15, abs=0)
+    vd = q("vdw").reshape(len(o["species"]), len(o["species"]), 8)
+    for a in range(len(o["species"])):
+        for b in range(len(o["species"])):
+            p = o["vdw"][a][b]
+            if p is None:
+                assert vd[a, b, 0] == 0
+            else:
+                ref = [p["type"], p["r2cut"], p["p0"], p["p1"], p["p2"], p["p3"], p["p4"], p["use_radii"]]
+                assert vd[a, b].tolist() == pytest.approx(ref, rel=1e-15, abs=0), (a, b)
+    assert [int(t) for t in q("types")] == o["types"]
+    for k in ("x", "y", "z"):
+        assert np.array_equal(q(k), np.array(o[k]))
+    return m, o
+
+
+def test_quirky_grammar(tmp_path):
+    d = str(tmp_path / "quirky")
+    write_quirky(d)
+    m, o = compare(d)
+    # first-match-wins: the second 'vdw' block is a comment; 'radi 0.2' parses the 0; the 'fenn' line's trailing 6 6 6 is ignored
+    assert o["vdw"][0][0]["r2cut"] == 16.0 and o["tstat_type"] == 2 and o["elec_type"] == 3 and o["rmax"] == 8.0
+    assert o["species"][1]["frozen"] == 1 and o["elecfield"] == [0.0, 0.0, 0.0] and o["nthread"] == [16, 48, 50]
+    assert o["vdw"][0][1]["type"] == 2 and o["vdw"][1][0]["p2"] == 12.5 and o["vdw"][1][1]["p4"] == 80.0
+
+
+def test_generated_inputs_round_trip(tmp_path):
+    case = inputs.config("F3")
+    case["nsteps"] = 77
+    d = str(tmp_path / "f3")
+    inputs.write_input_files(case, d)
+    m, o = compare(d)
+    assert o["nstep"] == 77 and o["elec_type"] == 3 and o["n_atoms"] == 4000
+    m2 = api.Model.from_case(case)
+    for k in ("rmax", "tkin", "scale", "scale2", "vdw", "species", "x", "types"):
+        assert np.array_equal(m.query(k), m2.query(k)), k
+
+
+def test_neutral_species_demote_electrostatics(tmp_path):
+    case = inputs.config("F1")
+    case.update(elec_type=3, rReal=8.0, alpha=0.4)
+    d = str(tmp_path / "neutral")
+    inputs.write_input_files(case, d)
+    m, o = compare(d)
+    assert o["elec_type"] == 0 and o["rmax"] == 6.5          # elec.cpp:52-56 ; sys_init.cpp:1060-1071
+
+
+@pytest.mark.parametrize("text,code", [("spec 1\nAr Ar 39.9 0 0\nvdw 1\nAr Ar lnjs 4 0.01 3.4\nbonds 2\n", "out of scope"),
+                                       ("vdw 1\nAr Ar lnjs 4 0.01 3.4\n", "ERROR[004]"),
+                                       ("spec 1\nAr Ar 39.9 0 0\nvdw 1\nAr Xe lnjs 4 0.01 3.4\n", "ERROR[005]"),
+                                       ("spec 1\nAr Ar 39.9 0 0\nvdw 1\nAr Ar morse 4 0.01 3.4\n", "ERROR[006]")])
+def test_error_reporting(tmp_path, text, code):
+    d = str(tmp_path / "bad")
+    write_quirky(d)
+    open(os.path.join(d, "field.txt"), "w").write(text)
+    with pytest.raises(api.AztotError) as ei:
+        api.Model.from_dir(d)
+    assert code in str(ei.value)
+
+
+def test_missing_files_and_scope(tmp_path):
+    with pytest.raises(api.AztotError) as ei:
+        api.Model.from_dir(str(tmp_path / "nowhere"))
+    assert "ERROR[001]" in str(ei.value)
+    d = str(tmp_path / "pme")
+    write_quirky(d)
+    open(os.path.join(d, "control.txt"), "w").write(QUIRKY_CONTROL.replace("elec\tfenn\t8.0\t0.4", "elec\tpme\t8.0\t0.4"))
+    m = api.Model.from_dir(d)
+    with pytest.raises(api.AztotError) as ei:     # reciprocal-space Ewald is out of scope: rejected when the model is finished
+        m.query("rmax")
+    assert "out of scope" in str(ei.value)
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present on this machine")
+@pytest.mark.parametrize("sub", ["case study 1", "case study 2", "src"])
+def test_reference_case_studies(sub):
+    m, o = compare(os.path.join(REF, sub))
+    if sub == "case study 1":
+        assert o["n_atoms"] == 40000 and o["elec_type"] == 0 and o["rmax"] == 4.0 and o["cell_list"] == 85.0 and o["tstat_type"] == 2
+    else:
+        assert o["n_atoms"] == 4000 and o["vdw"][0][0]["type"] == 7 and o["vdw"][0][0]["use_radii"] == 1 and o["rmax"] == 6.0
+
+
+def test_thermostat_tables_match_oracle():
+    from oracle import oracle
+    case = inputs.lj_case((3, 3, 3), a=5.26, seed=11, rc=6.5, T=298.0, tstat="radi", radii=[(2.73, 4.731, 0.2)])
+    m = api.Model.from_case(case)
+    o = oracle.Oracle(case)
+    assert np.array_equal(m.query("photons", seed=12345), o.photons())
+    uv = m.query("uvects").reshape(3, -1)
+    L = oracle.lib()
+    import ctypes as C
+    ux, uy, uz = np.empty(3072), np.empty(3072), np.empty(3072)
+    L.orc_unit_vectors(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in (ux, uy, uz)])
+    assert np.array_equal(uv[0], ux) and np.array_equal(uv[1], uy) and np.array_equal(uv[2], uz)
+    assert abs((uv ** 2).sum(axis=0) - 1.0).max() < 1e-15 and abs(uv.sum(axis=1)).max() < 1e-12
+    ph = o.photons()
+    kT = 8.617328270398135e-05 * 298.0
+    assert 4.0 * kT < ph.mean() < 6.0 * kT          # Gamma(5, kT) has mean 5 kT (temperature.cpp:28-89)
