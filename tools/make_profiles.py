@@ -1,0 +1,51 @@
+"""Copy the rocprofv3 summaries that back bench.py's roofline numbers from gpurun_out/ (scratch) into profiles/.
+
+  python tools/make_profiles.py <round-tag> <stats_dir> <fetch_dir> <write_dir> [workload] [n_gpus]
+HBM traffic per launch follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are collected in SEPARATE --pmc
+passes (TCC slot limit), are in KiB, and on gfx950 FETCH_SIZE reports exactly half of the bytes actually fetched
+(checked here on k_integrate2, whose traffic is known: 52 B/atom read, 24 B/atom written).
+"""
+import csv, glob, json, os, shutil, sys, collections
+
+tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+workload = sys.argv[5] if len(sys.argv) > 5 else "C4"
+ngpu = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
+for f in glob.glob(stats_dir + "/**/*kernel_stats.csv", recursive=True):
+    shutil.copy(f, os.path.join(P, "%s_rocprofv3_kernel_stats.csv" % tag))
+for f in glob.glob(stats_dir + "/bench_line.json"):
+    shutil.copy(f, os.path.join(P, "%s_bench_line_under_rocprofv3.json" % tag))
+
+
+def means(d, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == counter:
+                k = row["Kernel_Name"].split("(")[0].replace("void aztot::", "").replace("aztot::", "")
+                acc[k].append(float(row["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+fetch, write = means(fetch_dir, "FETCH_SIZE"), means(write_dir, "WRITE_SIZE")
+rows = []
+for k in sorted(set(fetch) | set(write)):
+    f, nf = fetch.get(k, (0.0, 0))
+    w, nw = write.get(k, (0.0, 0))
+    rows.append({"kernel": k, "dispatches": max(nf, nw), "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w,
+                 "hbm_read_bytes": 2.0 * f * 1024.0, "hbm_write_bytes": w * 1024.0, "hbm_bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0})
+with open(os.path.join(P, "%s_rocprofv3_pmc_hbm_traffic.csv" % tag), "w", newline="") as f:
+    wri = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    wri.writeheader()
+    wri.writerows(rows)
+tp = os.path.join(P, "pmc_traffic.json")
+rec = json.load(open(tp)) if os.path.exists(tp) else {}
+for r in rows:
+    name = {"k_pair_tile<1>": "pair_tile", "k_pair_tile<0>": "pair_tile", "k_pair_atom": "pair_atom"}.get(r["kernel"])
+    if name:
+        rec["%s:%s:%d" % (workload, name, ngpu)] = {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"], "round": tag, "kernel": r["kernel"],
+                                                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH doubled per MI355X_MICROARCH.md"}
+json.dump(rec, open(tp, "w"), indent=1)
+print(open(os.path.join(P, "%s_rocprofv3_pmc_hbm_traffic.csv" % tag)).read())
