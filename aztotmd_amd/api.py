@@ -72,7 +72,8 @@ EXPORTS = ("aztot_init_md", "aztot_model_create", "aztot_model_query", "aztot_fr
 
 
 def library_path():
-    return os.path.join(_HERE, "libaztot.so")
+    # AZTOT_LIB lets an experiment load another build of the SAME library (kernel A/B comparisons); never a fallback
+    return os.environ.get("AZTOT_LIB") or os.path.join(_HERE, "libaztot.so")
 
 
 def build_library(force=False):

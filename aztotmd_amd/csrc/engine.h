@@ -80,6 +80,7 @@ private:
     DevStats* dStats_ = nullptr;
     Counts* dCounts_ = nullptr;
     double *dPhotons_ = nullptr, *dUvx_ = nullptr, *dUvy_ = nullptr, *dUvz_ = nullptr;
+    double* dStage_ = nullptr;      // sub-totals of the two-level collect
     double* dEkGlobal_ = nullptr;   // kinetic energy over all ranks (equilibration scaling only)
     char* dMsg_[4] = {nullptr, nullptr, nullptr, nullptr};   // sendLeft, sendRight, fromLeft, fromRight
     MsgLayout lay_{};

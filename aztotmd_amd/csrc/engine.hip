@@ -220,6 +220,8 @@ void Engine::allocate()
     dCounts_ = (Counts*)alloc(sizeof(Counts));
     dChunkTot_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)(div_up(nCellAlloc_, kScanChunk) + 1));
     dEkGlobal_ = (double*)alloc(sizeof(double) * 2);
+    dStage_ = (double*)alloc(sizeof(double) * PS_COUNT * kCollectParts);
+    HIP_CHECK(hipMemsetAsync(dStage_, 0, sizeof(double) * PS_COUNT * kCollectParts, stream_));
     if (nranks_ > 1)
     {
         for (int k = 0; k < 4; k++) { dMsg_[k] = (char*)alloc(lay_.bytes()); HIP_CHECK(hipMemsetAsync(dMsg_[k], 0, lay_.bytes(), stream_)); }
@@ -363,9 +365,10 @@ void Engine::sort_and_forces(bool integrate_first)
 void Engine::collect_and_finalize(unsigned slotMask, bool advance)
 {
     timed("collect", [&] {
-        hipLaunchKernelGGL(k_collect, dim3(PS_COUNT), dim3(1024), 0, stream_, dPartials_, maxBlocks_, div_up(capacity_, kBlock), pairBlocksUsed_, dStats_, slotMask);
+        hipLaunchKernelGGL(k_collect, dim3(PS_COUNT * kCollectParts), dim3(256), 0, stream_, dPartials_, maxBlocks_, div_up(capacity_, kBlock), pairBlocksUsed_,
+                           dStage_, slotMask);
     });
-    timed("finalize", [&] { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, stream_, P_, dStats_, advance ? 1 : 0); });
+    timed("finalize", [&] { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, stream_, P_, dStats_, dStage_, slotMask, advance ? 1 : 0); });
 }
 
 void Engine::forces()

@@ -612,22 +612,39 @@ __global__ __launch_bounds__(kBlock) void k_post(StepParams P, SpecTable S, Atom
 // ------------------------------------------------------------------------------------------------
 // K1 + K13: fold the per-block partials into this rank's per-step sums (fixed order)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_collect(const double* __restrict__ partials, int maxBlocks, int nBlocksAtoms, int nBlocksPair,
-                                                  DevStats* st, unsigned slotMask)
+// two-level fixed-order sum: kCollectParts workgroups per slot each reduce a contiguous share of the per-block
+// partials, k_finalize adds the kCollectParts sub-totals in order
+constexpr int kCollectParts = 16;
+
+__global__ __launch_bounds__(256) void k_collect(const double* __restrict__ partials, int maxBlocks, int nBlocksAtoms, int nBlocksPair,
+                                                 double* __restrict__ stage, unsigned slotMask)
 {
-    __shared__ double scratch[16];
-    const int slot = blockIdx.x;                      // one workgroup per reduction slot
-    if (!((slotMask >> slot) & 1u)) return;
-    const int nb = (slot == PS_EVDW || slot == PS_ECOUL || slot == PS_DROPPED) ? nBlocksPair : nBlocksAtoms;
-    double v = reduce_slot(partials, maxBlocks, nb, slot, scratch);
-    if (threadIdx.x == 0) st->local[slot] = v;
+    __shared__ double scratch[4];
+    const int slot = blockIdx.x / kCollectParts, part = blockIdx.x % kCollectParts;
+    double v = 0.0;
+    if ((slotMask >> slot) & 1u)
+    {
+        const int nb = (slot == PS_EVDW || slot == PS_ECOUL || slot == PS_DROPPED) ? nBlocksPair : nBlocksAtoms;
+        const int per = (nb + kCollectParts - 1) / kCollectParts;
+        const int b0 = part * per, b1 = min(nb, b0 + per);
+        for (int b = b0 + threadIdx.x; b < b1; b += blockDim.x) v += partials[(size_t)slot * maxBlocks + b];
+    }
+    v = block_sum(v, scratch);
+    if (threadIdx.x == 0) stage[slot * kCollectParts + part] = v;
 }
 
 // reset_quantities + calc_quantities (cuMDfunc.cu:270, main.cu:121-194 ; serial calc_chars integrators.cpp:63-73).
 // Works on this rank's sums; the cross-rank sum is taken when the host asks for statistics (Engine::get_stats).
-__global__ void k_finalize(StepParams P, DevStats* st, int advance)
+__global__ void k_finalize(StepParams P, DevStats* st, const double* __restrict__ stage, unsigned slotMask, int advance)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int slot = 0; slot < PS_COUNT; slot++)
+        if ((slotMask >> slot) & 1u)
+        {
+            double v = 0.0;
+            for (int k = 0; k < kCollectParts; k++) v += stage[slot * kCollectParts + k];
+            st->local[slot] = v;
+        }
     const double* sums = st->local;
     st->engElecField = sums[PS_EFIELD];
     st->engVdW = sums[PS_EVDW];

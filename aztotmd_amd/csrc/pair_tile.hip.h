@@ -6,7 +6,9 @@
 //   * the neighbour stencil (2hw+1)^3 is walked on the fly; the periodic image shift is applied once per
 //     neighbour run while it is staged, so the inner loop has no minimum-image selects;
 //   * staging is a coalesced SoA load of whole z-runs (cells that are contiguous in the sorted arrays), pruned
-//     against the centre cell's bounding box and packed into LDS with wave ballot + popcount prefix;
+//     against the centre cell's bounding box and packed into LDS with wave ballot + popcount prefix; the runs are
+//     looked up by all lanes in parallel and loaded in groups of four so that a wave pays ~4 memory round trips
+//     per cell instead of ~20;
 //   * lanes are split (i-slot, j-slice): 16 atoms x 4 slices for the typical 13-atom cell, so ~85 % of the lanes
 //     work instead of 21 %; slices are folded with two xor-shuffles in a fixed order;
 //   * every atom's force is the sum over ALL its neighbours (no Newton-3 halving): written once, no atomics,
@@ -50,6 +52,22 @@ __device__ __forceinline__ double fast_rcp(double x)
     return y;
 }
 
+// number of set bits of a 64-bit ballot below this lane: two v_mbcnt instructions
+__device__ __forceinline__ int lanes_below(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// 8-byte element j of a device array through a 32-bit byte offset (scalar base + vector offset addressing)
+__device__ __forceinline__ double ld_f64(const double* __restrict__ base, int j)
+{
+    return *(const double*)((const char*)base + ((unsigned)j << 3));
+}
+__device__ __forceinline__ int ld_i32(const int32_t* __restrict__ base, int j)
+{
+    return *(const int32_t*)((const char*)base + ((unsigned)j << 2));
+}
+
 // The two passes over one staged chunk; LG = log2(i-slots), NS = 64 >> LG = lanes (slices) per i-atom.
 //   pass 1  distance tests only (7 fp64 ops per candidate); hits are recorded in three per-lane 32-bit masks
 //   pass 2  every lane pops its own hits (from whichever word still has one), so the potential runs on densely
@@ -65,6 +83,8 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
 {
     constexpr int NS = kWave >> LG;
     const int iters = ((T + NS - 1) / NS + 3) & ~3;        // per-lane candidates, rounded up to the unroll factor
+    const double r2Filter = P.r2Max * (1.0 + 1e-13);       // conservative pass-1 threshold (see below)
+    int nDropHalf = 0;
     for (int rb = 0; rb < iters; rb += 96)
     {
         uint32_t m[3];
@@ -73,7 +93,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
         {
             const int tb = rb + w * 32;
             const int nb = min(32, iters - tb);            // multiple of 4, may be <= 0
-            uint32_t mm = 0u;
+            uint32_t miss = 0xFFFFFFFFu;                   // one bit per candidate, 1 = outside the cut-off
             const double* px = &tx[tb * NS + slice];
             const double* py = &ty[tb * NS + slice];
             const double* pz = &tz[tb * NS + slice];
@@ -82,22 +102,25 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
 #pragma unroll
                 for (int u = 0; u < 4; u++)
                 {
+                    // 7 VALU per candidate: 3 subtractions, 3 FMAs that leave d = rc^2(1+eps) - r^2, and one v_alignbit
+                    // that shifts the sign of d into the mask.  The filter is conservative by eps; pass 2 applies the
+                    // exact r^2 <= rc^2 test of the reference (pair_inter integrators.cpp:148).
                     const double dx = xi - px[u * NS], dy = yi - py[u * NS], dz = zi - pz[u * NS];
-                    const double r2 = dx * dx + dy * dy + dz * dz;
-                    mm = (mm << 1) | (uint32_t)(r2 <= P.r2Max);      // newest candidate in bit 0
+                    const double d = fma(-dz, dz, fma(-dy, dy, fma(-dx, dx, r2Filter)));
+                    miss = __builtin_amdgcn_alignbit(miss, (uint32_t)(__double_as_longlong(d) >> 32), 31);   // newest candidate in bit 0
                 }
                 px += 4 * NS; py += 4 * NS; pz += 4 * NS;
             }
             // left-align: candidate number b of this word sits at bit 31 - b, whatever the word length
-            m[w] = (nb > 0) ? (mm << (32 - nb)) : 0u;
+            m[w] = (nb > 0) ? (~miss << (32 - nb)) : 0u;
         }
         if (P.pad0 & 2) { acc.fx += (double)(m[0] ^ m[1] ^ m[2]); m[0] = m[1] = m[2] = 0u; }
         const int k0 = rb * NS + slice;
         while (__any((m[0] | m[1] | m[2]) != 0u))
         {
             // pop the first remaining hit of this lane: word selection by two compares, then one clz.  The body is
-            // branch-free (lanes without a hit run on a dummy candidate and are masked out at the end): a conditional
-            // body makes the compiler shuffle all accumulators through copies on every iteration.
+            // branch-free (lanes without a hit run on a dummy candidate and are masked out): a conditional body makes
+            // the compiler shuffle all accumulators through copies on every iteration.
             const bool h0 = m[0] != 0u, h1 = m[1] != 0u;
             const uint32_t mw = h0 ? m[0] : (h1 ? m[1] : m[2]);
             const bool live = mw != 0u;
@@ -112,24 +135,26 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
             const double r2 = dx * dx + dy * dy + dz * dz;
             if (MODE == 1)
             {   // fer_lj vdw.cpp:16-26 ; pair_inter integrators.cpp:139-185.  The atom itself (r2 == 0 exactly: its own
-                // cell is part of the tile, unshifted) and pairs beyond the potential's own cut-off are masked out at the
-                // end; 1/0 = inf only ever meets a select.
-                const double r2i = fast_rcp(r2);
+                // cell is part of the tile, unshifted), candidates the conservative filter let through and dead lanes
+                // are pushed out to a huge r2, where sr6 underflows to exactly 0 and with it energy and force.
+                const bool pairOk = live & (r2 > 0.0) & (r2 <= lj.r2cut);
+                const double r2s = pairOk ? r2 : 1e300;
+                const double r2i = fast_rcp(r2s);
                 const double sr2 = lj.p1 * r2i;
                 const double sr6 = sr2 * sr2 * sr2;
-                const double e = lj.p0 * sr6 * (sr6 - 1.0);
+                acc.eV = fma(0.5 * lj.p0, sr6 * (sr6 - 1.0), acc.eV);
                 const double f = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
-                const bool pairOk = live & (r2 > 0.0) & (r2 <= lj.r2cut);
-                const bool forceOk = pairOk & !(f * f > 1e10);           // integrators.cpp:170-174
-                const double fm = forceOk ? f : 0.0;
-                acc.eV += pairOk ? 0.5 * e : 0.0;
-                acc.dropped += (pairOk & !forceOk) ? 0.5 : 0.0;
-                acc.fx += fm * dx; acc.fy += fm * dy; acc.fz += fm * dz;
+                const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
+                nDropHalf += __popcll(__ballot(tooBig));
+                const double fm = tooBig ? 0.0 : f;
+                acc.fx = fma(fm, dx, acc.fx); acc.fy = fma(fm, dy, acc.fy); acc.fz = fma(fm, dz, acc.fz);
             }
-            else if (live && r2 > 0.0)
+            else if (live && r2 > 0.0 && r2 <= P.r2Max)
                 pair_visit(P, S, pots, dx, dy, dz, r2, ti, ttyp[k], radi, trad[k], acc);
         }
     }
+    // dropped pairs were counted per wave (ballot popcount); book the wave total on lane 0 in "half pair" units
+    if (MODE == 1 && threadIdx.x == 0) acc.dropped += 0.5 * (double)nDropHalf;
 }
 
 template <int MODE>   // 0: generic (species table, Coulomb, radii) ; 1: one species, Lennard-Jones only
@@ -140,6 +165,7 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
     __shared__ double tx[kTileLds], ty[kTileLds], tz[kTileLds];
     __shared__ int32_t ttyp[MODE == 0 ? kTileLds : 1];
     __shared__ double trad[MODE == 0 ? kTileLds : 1];
+    __shared__ int32_t entJ[kWave], entN[kWave], entC[kWave];       // staging table: first atom, count (<= 64), image-shift code
 
     const int lane = threadIdx.x;
     // XCD-aware mapping: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous run of cells
@@ -193,57 +219,111 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
                 T = 0;
             };
 
-            // walk the stencil: for every (x, y) neighbour column the z-neighbours form at most three contiguous runs
-            for (int ox = 0; ox < P.nOff[0]; ox++)
+            // ---- staging.  Memory latency, not bandwidth, is what staging costs (each wave would otherwise walk ~10
+            // dependent s_load -> global_load round trips), so it is organised as few, wide round trips:
+            //   1. the lanes look up ALL z-runs of the stencil in parallel (one lane per (x-offset, y-offset, segment));
+            //   2. non-empty runs are packed into a small LDS table (<= 64 atoms per entry);
+            //   3. entries are consumed in groups of up to four: all their coordinate loads are issued before the first
+            //      one is used.
+            const int nSegTot = P.nOff[0] * P.nOff[1] * 3;
+            const int rcpOff1 = 65536 / P.nOff[1] + 1;
+            for (int sg0 = 0; sg0 < nSegTot; sg0 += kWave)
             {
-                int nx = lx + ox - P.hw[0];
-                double shx = 0.0;
-                if (P.nranks > 1)
-                {   // slab window: ghost layers are resident; their coordinates are global, so shift across the seam
-                    const int gx = nx + P.cx0;
-                    if (gx < 0) shx = -P.L[0]; else if (gx >= P.nc[0]) shx = P.L[0];
-                }
-                else if (nx < 0) { nx += P.nc[0]; shx = -P.L[0]; }
-                else if (nx >= P.nc[0]) { nx -= P.nc[0]; shx = P.L[0]; }
-                for (int oy = 0; oy < P.nOff[1]; oy++)
+                int rjb = 0, rn = 0, rcode = 0;
                 {
-                    int ny = cy + oy - P.hw[1];
-                    double shy = 0.0;
-                    if (ny < 0) { ny += ncy; shy = -P.L[1]; } else if (ny >= ncy) { ny -= ncy; shy = P.L[1]; }
-                    const int colBase = (nx * ncy + ny) * ncz;
+                    const int sg = sg0 + lane;
+                    // sg = (ox * nOff1 + oy) * 3 + seg, decoded with multiply-shift reciprocals (operands are < 2^10)
+                    const int col = (sg * 21846) >> 16, seg = sg - 3 * col;
+                    const int ox = (col * rcpOff1) >> 16, oy = col - ox * P.nOff[1];
+                    int nx = lx + ox - P.hw[0], cxs = 1;                      // shift codes: 0 -> -L, 1 -> 0, 2 -> +L
+                    if (P.nranks > 1)
+                    {   // slab window: ghost layers are resident; their coordinates are global, so shift across the seam
+                        const int gx = nx + P.cx0;
+                        if (gx < 0) cxs = 0; else if (gx >= P.nc[0]) cxs = 2;
+                    }
+                    else if (nx < 0) { nx += P.nc[0]; cxs = 0; }
+                    else if (nx >= P.nc[0]) { nx -= P.nc[0]; cxs = 2; }
+                    int ny = cy + oy - P.hw[1], cys = 1;
+                    if (ny < 0) { ny += ncy; cys = 0; } else if (ny >= ncy) { ny -= ncy; cys = 2; }
                     const int zlo = cz - P.hw[2], zhi = cz + P.hw[2];
-                    for (int seg = 0; seg < 3; seg++)
+                    int zs, ze, czs = 1;
+                    bool have = sg < nSegTot;
+                    if (seg == 0) { zs = max(zlo, 0); ze = min(zhi, ncz - 1); }
+                    else if (seg == 1) { have = have && zlo < 0; zs = zlo + ncz; ze = ncz - 1; czs = 0; }
+                    else { have = have && zhi >= ncz; zs = 0; ze = zhi - ncz; czs = 2; }
+                    if (have)
                     {
-                        int zs, ze; double shz;
-                        if (seg == 0) { zs = max(zlo, 0); ze = min(zhi, ncz - 1); shz = 0.0; }
-                        else if (seg == 1) { if (zlo >= 0) continue; zs = zlo + ncz; ze = ncz - 1; shz = -P.L[2]; }
-                        else { if (zhi < ncz) continue; zs = 0; ze = zhi - ncz; shz = P.L[2]; }
-                        const int jb = cellStart[colBase + zs], je = cellStart[colBase + ze + 1];
-                        for (int j0 = jb; j0 < je; j0 += kWave)
+                        const int colBase = (nx * ncy + ny) * ncz;
+                        rjb = cellStart[colBase + zs];
+                        rn = cellStart[colBase + ze + 1] - rjb;
+                        rcode = cxs | (cys << 2) | (czs << 4);
+                    }
+                }
+                while (__any(rn > 0))
+                {
+                    // one table entry (<= 64 atoms) per run that still has atoms
+                    const unsigned long long emask = __ballot(rn > 0);
+                    const int nEnt = __popcll(emask);
+                    if (rn > 0)
+                    {
+                        const int pe = lanes_below(emask);
+                        entJ[pe] = rjb; entN[pe] = min(rn, kWave); entC[pe] = rcode;
+                        rjb += kWave; rn -= kWave;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    int e = 0;
+                    while (e < nEnt)
+                    {
+                        const int g = min(min(4, nEnt - e), (kTileCap - T) >> 6);
+                        if (g == 0) { process(); continue; }                   // tile full: run the passes, then go on filling
+                        const int le = min(e + (lane & 3), nEnt - 1);
+                        const int vj = entJ[le], vn = entN[le], vc = entC[le];
+                        double gx[4], gy[4], gz[4], grad[4];
+                        int gtyp[4], gjn[4], gcode[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
                         {
-                            if (T + kWave > kTileCap) process();
-                            const int j = j0 + lane;
-                            bool keep = false;
-                            double xj = 0, yj = 0, zj = 0;
-                            if (j < je)
+                            const int j = __builtin_amdgcn_readlane(vj, u) + lane;
+                            gjn[u] = (u < g) ? __builtin_amdgcn_readlane(vn, u) : 0;
+                            gcode[u] = __builtin_amdgcn_readlane(vc, u);
+                            gx[u] = gy[u] = gz[u] = 0.0; grad[u] = 0.0; gtyp[u] = 0;
+                            if (lane < gjn[u])
                             {
-                                xj = A.x[j] + shx; yj = A.y[j] + shy; zj = A.z[j] + shz;
+                                gx[u] = ld_f64(A.x, j); gy[u] = ld_f64(A.y, j); gz[u] = ld_f64(A.z, j);
+                                if (MODE == 0) { gtyp[u] = ld_i32(A.type, j); if (P.use_radii) grad[u] = ld_f64(A.rad, j); }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                        {
+                            if (u < g)
+                            {
+                                double xj = gx[u], yj = gy[u], zj = gz[u];
+                                if (gcode[u] != 0x15)
+                                {   // this run is a periodic image (wave-uniform branch; only boundary cells take it)
+                                    const int c0 = gcode[u] & 3, c1 = (gcode[u] >> 2) & 3, c2 = (gcode[u] >> 4) & 3;
+                                    xj += c0 == 0 ? -P.L[0] : (c0 == 2 ? P.L[0] : 0.0);
+                                    yj += c1 == 0 ? -P.L[1] : (c1 == 2 ? P.L[1] : 0.0);
+                                    zj += c2 == 0 ? -P.L[2] : (c2 == 2 ? P.L[2] : 0.0);
+                                }
                                 // distance from the centre cell's box: atoms farther than the cut-off cannot reach any atom in it
                                 const double bx = fmax(fmax(lo0 - xj, xj - hi0), 0.0);
                                 const double by = fmax(fmax(lo1 - yj, yj - hi1), 0.0);
                                 const double bz = fmax(fmax(lo2 - zj, zj - hi2), 0.0);
-                                keep = (bx * bx + by * by + bz * bz) <= P.r2Max;
+                                const bool keep = (lane < gjn[u]) && (bx * bx + by * by + bz * bz) <= P.r2Max;
+                                const unsigned long long mask = __ballot(keep);
+                                if (keep)
+                                {
+                                    const int pp = T + lanes_below(mask);
+                                    tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
+                                    if (MODE == 0) { ttyp[pp] = gtyp[u]; trad[pp] = grad[u]; }
+                                }
+                                T += __popcll(mask);
                             }
-                            const unsigned long long mask = __ballot(keep);
-                            if (keep)
-                            {
-                                const int p = T + __popcll(mask & ((1ULL << lane) - 1ULL));
-                                tx[p] = xj; ty[p] = yj; tz[p] = zj;
-                                if (MODE == 0) { ttyp[p] = A.type[j]; trad[p] = P.use_radii ? A.rad[j] : 0.0; }
-                            }
-                            T += __popcll(mask);
                         }
+                        e += g;
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
             process();
