@@ -65,7 +65,7 @@ class _State(C.Structure):
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
 
-EXPORTS = ("aztot_init_md", "aztot_model_create", "aztot_model_query", "aztot_free_md", "aztot_default_options",
+EXPORTS = ("aztot_init_md", "aztot_model_create", "aztot_model_query", "aztot_model_species_name", "aztot_free_md", "aztot_default_options",
            "aztot_init_device", "aztot_free_device", "aztot_step", "aztot_forces", "aztot_get_stats", "aztot_md_to_host",
            "aztot_set_state", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id",
            "aztot_init_device_slab", "aztot_last_error", "aztot_version")
@@ -84,7 +84,7 @@ def build_library(force=False):
     hdr = os.path.join(os.path.dirname(_HERE), "include", "aztot.h")
     newest = max(newest, os.path.getmtime(hdr))
     if force or not os.path.exists(so) or os.path.getmtime(so) < newest:
-        subprocess.check_call(["make", "-C", src_dir], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", src_dir, "all"], stdout=subprocess.DEVNULL)
     return so
 
 

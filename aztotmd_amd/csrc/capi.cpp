@@ -1,5 +1,6 @@
 // C ABI (include/aztot.h) over the C++ host side.  Every entry point catches exceptions and turns them
 // into an error code + thread-local message (the reference prints "ERROR[..]" and returns 0).
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -68,6 +69,13 @@ int aztot_model_create(const aztot_system* sys, aztot_model** out)
 }
 
 void aztot_free_md(aztot_model* m) { delete m; }
+
+int aztot_model_species_name(const aztot_model* m, int i, char* buf, int cap)
+{
+    if (!m || !buf || cap <= 0 || i < 0 || i >= m->m.nSpec()) return fail(AZTOT_ERR_ARG, "bad argument");
+    std::snprintf(buf, (size_t)cap, "%s", m->m.species[i].name.c_str());
+    return AZTOT_OK;
+}
 
 // Keys (all values returned as doubles):
 //  n_atoms n_species box dt nstep nequil eqfreq temperature tstat_type elec_type r_real alpha scale scale2 daipi2

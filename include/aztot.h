@@ -131,6 +131,8 @@ int aztot_model_create(const aztot_system *sys, aztot_model **out);
 /* string-keyed read-out of parsed/derived values as doubles; returns the number of values written
    (or needed, if cap is too small), negative on unknown key.  Keys: see aztotmd_amd/csrc/capi.cpp */
 int aztot_model_query(const aztot_model *m, const char *key, double *out, int cap);
+/* name of species i as written in field.txt (NUL-terminated, at most cap-1 characters) */
+int aztot_model_species_name(const aztot_model *m, int i, char *buf, int cap);
 void aztot_free_md(aztot_model *m);
 
 /* ---- device: replaces init_cudaMD / md_to_host / free_device_md (cuInit.h:4,6,7) --------------------- */

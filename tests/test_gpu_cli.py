@@ -1,0 +1,55 @@
+"""GPU test of the command-line driver (the reference program's surface: four input files in, stat.dat / revcon.xyz /
+velocities.dat / tchars.dat out) on a 'case study 2'-style system: 4 000 atoms, surk radius-dependent potential fed by the
+radiative thermostat, cell_list below the cut-off, equilibration scaling.  Checked against the CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from aztotmd_amd import inputs
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def case_study_2_like():
+    pos, box = inputs.fcc_positions((10, 10, 10), 3.5, 0.12, 42)
+    pos = np.round(pos, 6)
+    box = np.round(box, 6)
+    pos[pos >= box] = 0.0
+    N = len(pos)
+    return {"box": box.tolist(), "dt": 0.001, "nsteps": 60, "species": [(39.9, 0.0)], "names": ["Ar"], "types": np.zeros(N, dtype=np.int32),
+            "vdw": [(0, 0, 7, 6.0, [75.0, 8.0, 1.0, 1.0])], "radii": [(2.73, 4.731, 0.2)], "x": pos[:, 0].copy(), "y": pos[:, 1].copy(),
+            "z": pos[:, 2].copy(), "vx": np.zeros(N), "vy": np.zeros(N), "vz": np.zeros(N), "T": 500.0, "tstat_type": 2, "nEq": 40,
+            "freqEq": 10, "cell_list": 2.7, "use_clist": 1, "elec_type": 0}
+
+
+def test_cli_reproduces_oracle(tmp_path):
+    case = case_study_2_like()
+    d = str(tmp_path / "run")
+    inputs.write_input_files(case, d, stat=20)
+    exe = os.path.join(ROOT, "aztotmd_amd", "aztotmd")
+    r = subprocess.run([exe, d, "--out", d], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    o = oracle.Oracle(case)           # the GPU program starts from F = 0: no initial force evaluation
+    rows = [ln.split("\t") for ln in open(os.path.join(d, "stat.dat")).read().strip().splitlines()]
+    assert rows[0][:7] == ["time", "step", "engTot", "engKin", "engVdW", "engCoul1", "engCoul2"] and rows[0][7] == "engTerm"
+    assert len(rows) == 2 + 3
+    for row in rows[2:]:
+        o.step(20)
+        st = o.stats()
+        assert int(row[1]) == int(st["iStep"])
+        for col, key in ((2, "engTot"), (3, "engKin"), (4, "engVdW"), (7, "engTemp")):
+            assert abs(float(row[col]) - st[key]) <= 2e-6 + 1e-9 * abs(st[key]), (row[1], key, row[col], st[key])
+    s = o.state()
+    rev = open(os.path.join(d, "revcon.xyz")).read().splitlines()
+    assert int(rev[0]) == 4000 and rev[1].split()[0] == "1"
+    xyz = np.array([[float(v) for v in ln.split()[1:4]] for ln in rev[2:]])
+    for k, c in enumerate("xyz"):
+        assert np.abs(xyz[:, k] - s[c]).max() < 2e-6
+    vel = np.loadtxt(os.path.join(d, "velocities.dat"), skiprows=1)
+    assert vel.shape == (4000, 5) and np.abs(vel[:, 2] - s["vx"]).max() < 2e-6
+    tch = np.loadtxt(os.path.join(d, "tchars.dat"), skiprows=1)
+    assert np.abs(tch[:, 1] - s["U"]).max() < 2e-6 and np.abs(tch[:, 2] - s["rad"]).max() < 2e-6
