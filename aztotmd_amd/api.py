@@ -227,7 +227,12 @@ class Engine:
             _check(L.aztot_init_device(model.h, C.byref(o), C.byref(self.h)))
         else:
             idb = slab.get("rccl_id")
-            if idb is not None:
+            if slab.get("loopback"):
+                # measurement aid: one rank of an N-rank decomposition exchanging with itself (see LoopbackExchanger)
+                o.reserved[1] = 1
+                _check(L.aztot_init_device_slab(model.h, C.byref(o), slab["rank"], slab["nranks"], None, SENDRECV_FN(), ALLREDUCE_FN(), None,
+                                                C.byref(self.h)))
+            elif idb is not None:
                 buf = C.create_string_buffer(bytes(idb), len(idb))
                 self._cb = (buf,)
                 _check(L.aztot_init_device_slab(model.h, C.byref(o), slab["rank"], slab["nranks"], C.cast(buf, C.c_void_p),

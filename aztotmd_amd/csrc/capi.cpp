@@ -182,7 +182,7 @@ static int init_device_common(const aztot_model* h, const aztot_options* opt, in
                 md->xch.reset(new RcclExchanger(rank, nranks, id_bytes));
             }
             else if (sr && ar) md->xch.reset(new CallbackExchanger(sr, ar, ctx));
-            else throw std::runtime_error("slab: neither an RCCL id nor exchange callbacks were given");
+            else if (!o.reserved[1]) throw std::runtime_error("slab: neither an RCCL id nor exchange callbacks were given");
         }
         md->eng.reset(new Engine(m, o, rank, nranks, md->xch.get()));
         *out = md.release();

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -24,7 +25,9 @@ struct KernelTimer
     long long calls = 0;
 };
 
-class Exchanger;   // slab halo / migration transport (RCCL or host-staged callback)
+}  // namespace aztot
+#include "exchange.h"
+namespace aztot {
 
 class Engine
 {
@@ -51,7 +54,8 @@ private:
     void launch_step_kernels();
     void launch_pair();
     void exchange_halo();
-    void collect_and_finalize(unsigned slotMask, bool advance);
+    void collect_and_finalize(unsigned slotMask);
+    void finish_steps();
     void check_overflow();
     void sync();
     template <typename F> void timed(const char* name, F&& launch);
@@ -64,6 +68,7 @@ private:
     SpecTable S_{};
     int rank_, nranks_;
     Exchanger* xch_;
+    std::unique_ptr<Exchanger> ownedXch_;
 
     hipStream_t stream_ = nullptr;
     int capacity_ = 0;          // atoms that fit in the per-atom arrays (owned + ghosts + slack)

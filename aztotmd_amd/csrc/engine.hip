@@ -128,7 +128,7 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
     HIP_CHECK(hipSetDevice(opt_.device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     profile_ = opt_.profile != 0;
-    if (nranks_ > 1 && !xch_) throw std::runtime_error("slab decomposition needs an exchanger");
+    if (nranks_ > 1 && !xch_ && !opt_.reserved[1]) throw std::runtime_error("slab decomposition needs an exchanger");
 
     const Model& m = model_;
     P_.nSpec = m.nSpec();
@@ -159,6 +159,12 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
     }
     choose_cells();
     allocate();
+    if (nranks_ > 1 && !xch_)
+    {   // options.reserved[1]: loopback measurement mode (see LoopbackExchanger)
+        ownedXch_.reset(new LoopbackExchanger((P_.ncxLocal - 2 * P_.hw[0]) * P_.csz[0], P_.L[0], lay_.mig_offset(), lay_.halo_offset(),
+                                              sizeof(MigRec), sizeof(HaloRec)));
+        xch_ = ownedXch_.get();
+    }
     upload_initial();
 }
 
@@ -307,21 +313,15 @@ void Engine::launch_pair()
     pairBlocksUsed_ = (variant == 2) ? pair_tile_grid(P_) : div_up(capacity_, kBlock);
 }
 
-// one message to each x-neighbour: migrants + halo (slab.hip.h)
+// one message to each x-neighbour: migrants + halo (packed by k_integrate1_bin; protocol in slab.hip.h)
 void Engine::exchange_halo()
 {
-    const int gridAtoms = div_up(capacity_, kBlock);
-    HIP_CHECK(hipMemsetAsync(dMsg_[0], 0, sizeof(SendHeader), stream_));
-    HIP_CHECK(hipMemsetAsync(dMsg_[1], 0, sizeof(SendHeader), stream_));
-    timed("pack_halo", [&] {
-        hipLaunchKernelGGL(k_pack, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, cur(), dCounts_, dCellOf_, lay_, dMsg_[0], dMsg_[1]);
-    });
     const int left = (rank_ + nranks_ - 1) % nranks_, right = (rank_ + 1) % nranks_;
     timed("exchange", [&] { xch_->exchange(left, right, dMsg_[0], dMsg_[1], dMsg_[2], dMsg_[3], lay_.bytes(), stream_); });
     const int recvCap = 2 * (lay_.migCap + lay_.haloCap);
     timed("unpack_halo", [&] {
         hipLaunchKernelGGL(k_unpack, dim3(div_up(recvCap, kBlock)), dim3(kBlock), 0, stream_, P_, cur(), dCounts_, capacity_, lay_, dMsg_[2], dMsg_[3],
-                           dCellOf_, dSlotOf_, dCellCount_);
+                           dCellOf_, dSlotOf_, dCellCount_, dMsg_[0], dMsg_[1]);
     });
 }
 
@@ -334,14 +334,14 @@ void Engine::sort_and_forces(bool integrate_first)
     if (integrate_first)
         timed("integrate1_bin", [&] {
             hipLaunchKernelGGL(k_integrate1_bin<true>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
-                               dCellCount_, dPartials_, maxBlocks_);
+                               dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1]);
         });
     else
     {
         HIP_CHECK(hipMemsetAsync(dCellCount_, 0, sizeof(int32_t) * (size_t)(nCellAlloc_ + 1), stream_));
         timed("bin", [&] {
             hipLaunchKernelGGL(k_integrate1_bin<false>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
-                               dCellCount_, dPartials_, maxBlocks_);
+                               dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1]);
         });
     }
     if (nranks_ > 1) exchange_halo();
@@ -362,13 +362,13 @@ void Engine::sort_and_forces(bool integrate_first)
     launch_pair();
 }
 
-void Engine::collect_and_finalize(unsigned slotMask, bool advance)
+void Engine::collect_and_finalize(unsigned slotMask)
 {
     timed("collect", [&] {
         hipLaunchKernelGGL(k_collect, dim3(PS_COUNT * kCollectParts), dim3(256), 0, stream_, dPartials_, maxBlocks_, div_up(capacity_, kBlock), pairBlocksUsed_,
                            dStage_, slotMask);
     });
-    timed("finalize", [&] { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, stream_, P_, dStats_, dStage_, slotMask, advance ? 1 : 0); });
+    timed("finalize", [&] { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, stream_, P_, dStats_, dStage_, slotMask); });
 }
 
 void Engine::forces()
@@ -376,7 +376,7 @@ void Engine::forces()
     sort_and_forces(false);
     // energies of this configuration; kinetic energy and wall counters are left untouched
     const unsigned mask = (1u << PS_EVDW) | (1u << PS_ECOUL) | (1u << PS_DROPPED);
-    collect_and_finalize(mask, false);
+    collect_and_finalize(mask);
     HIP_CHECK(hipMemsetAsync(dCellCount_, 0, sizeof(int32_t) * (size_t)(nCellAlloc_ + 1), stream_));
     sync();
     check_overflow();
@@ -391,9 +391,8 @@ void Engine::launch_step_kernels()
     sort_and_forces(true);
     timed("integrate2", [&] {
         hipLaunchKernelGGL(k_integrate2, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal, dPartials_,
-                           maxBlocks_);
+                           maxBlocks_, dStats_);
     });
-    unsigned mask = (1u << PS_COUNT) - 1u;
     const bool equil = P_.nEq > 0;
     if (equil)
     {
@@ -409,16 +408,22 @@ void Engine::launch_step_kernels()
             HIP_CHECK(hipMemcpyAsync(dEkGlobal_, &ek, sizeof(double), hipMemcpyHostToDevice, stream_));
         }
         timed("scale_decision", [&] { hipLaunchKernelGGL(k_scale_decision, dim3(1), dim3(64), 0, stream_, P_, dStats_, dEkGlobal_); });
-        mask &= ~(1u << PS_EKIN);
     }
     if (equil || P_.tstat == AZTOT_TSTAT_RADI)
         timed("post_tstat", [&] {
             hipLaunchKernelGGL(k_post, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dStats_, dPhotons_, dUvx_, dUvy_, dUvz_,
                                dPartials_, maxBlocks_);
         });
-    else
-        mask &= ~(1u << PS_ETEMP);
-    collect_and_finalize(mask, true);
+}
+
+// the per-block partial sums are folded into the statistics only when somebody can look at them: at the end of a
+// step() call (energies are those of the last step; wall momenta / crossing counts pile up in between)
+void Engine::finish_steps()
+{
+    unsigned mask = (1u << PS_COUNT) - 1u;
+    if (P_.nEq > 0) mask &= ~(1u << PS_EKIN);            // k_reduce_kin / k_scale_decision own engKin while equilibrating
+    if (!(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_RADI)) mask &= ~(1u << PS_ETEMP);
+    collect_and_finalize(mask);
 }
 
 void Engine::step(int nsteps)
@@ -445,6 +450,7 @@ void Engine::step(int nsteps)
         while (nsteps - done >= 2) { HIP_CHECK(hipGraphLaunch(graphExec_[g], stream_)); done += 2; }
     }
     for (; done < nsteps; done++) launch_step_kernels();
+    finish_steps();
     sync();
     check_overflow();
 }

@@ -40,6 +40,35 @@ void CallbackExchanger::allreduce_sum(double* host, int n, hipStream_t)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// loopback transport (measurement aid)
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_loopback_shift(char* msg, size_t migOff, size_t haloOff, size_t migStride, size_t haloStride, double shift, double L)
+{
+    const int32_t* hdr = (const int32_t*)msg;
+    const int nMig = hdr[0], nHalo = hdr[1];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double* px = nullptr;
+    if (t < nMig) px = (double*)(msg + migOff + (size_t)t * migStride);
+    else if (t - nMig < nHalo) px = (double*)(msg + haloOff + (size_t)(t - nMig) * haloStride);
+    if (px)
+    {
+        double x = *px + shift;
+        if (x < 0) x += L; else if (x >= L) x -= L;
+        *px = x;
+    }
+}
+
+void LoopbackExchanger::exchange(int, int, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
+                                 hipStream_t stream)
+{
+    HIP_CHECK(hipMemcpyAsync(dFromRight, dSendLeft, bytes, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(dFromLeft, dSendRight, bytes, hipMemcpyDeviceToDevice, stream));
+    const int n = (int)((bytes - haloOff_) / haloStride_ + (haloOff_ - migOff_) / migStride_);
+    hipLaunchKernelGGL(k_loopback_shift, dim3((n + 255) / 256), dim3(256), 0, stream, (char*)dFromRight, migOff_, haloOff_, migStride_, haloStride_, w_, L_);
+    hipLaunchKernelGGL(k_loopback_shift, dim3((n + 255) / 256), dim3(256), 0, stream, (char*)dFromLeft, migOff_, haloOff_, migStride_, haloStride_, -w_, L_);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // RCCL transport
 // ---------------------------------------------------------------------------------------------------
 namespace {

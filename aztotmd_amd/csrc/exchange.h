@@ -43,6 +43,24 @@ private:
     std::vector<char> hs_[2], hr_[2];
 };
 
+// Measurement aid: ONE rank of an N-rank decomposition talks to itself.  What it sends leftward comes back as if the right
+// neighbour had sent it (x shifted by one slab width) and vice versa, so the rank sees the message sizes, ghost counts and
+// kernel shapes of a real N-rank run on a single GPU.  The physics is that of a system made of N copies of this slab.
+class LoopbackExchanger : public Exchanger
+{
+public:
+    LoopbackExchanger(double slabWidth, double boxLength, size_t migOffset, size_t haloOffset, size_t migStride, size_t haloStride)
+        : w_(slabWidth), L_(boxLength), migOff_(migOffset), haloOff_(haloOffset), migStride_(migStride), haloStride_(haloStride) {}
+    void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
+                  hipStream_t stream) override;
+    void allreduce_sum(double*, int, hipStream_t) override {}
+    bool device_side() const override { return true; }
+
+private:
+    double w_, L_;
+    size_t migOff_, haloOff_, migStride_, haloStride_;
+};
+
 class RcclExchanger : public Exchanger
 {
 public:

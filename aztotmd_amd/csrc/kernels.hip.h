@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_md.h"
+#include "msg_layout.h"
 #include "rng.h"
 
 namespace aztot {
@@ -53,6 +54,13 @@ __device__ __forceinline__ void put_partial(double* partials, int maxBlocks, int
 {
     partials[(size_t)slot * maxBlocks + blockIdx.x] = v;
 }
+// running sums (wall momenta, crossing counts, dropped pairs) pile up in the block's own entry until k_collect reads and
+// clears them: the reduction runs only when the host looks at the statistics, not every step
+__device__ __forceinline__ void add_partial(double* partials, int maxBlocks, int slot, double v)
+{
+    partials[(size_t)slot * maxBlocks + blockIdx.x] += v;
+}
+__device__ __forceinline__ bool slot_accumulates(int slot) { return (slot >= PS_MOM_XN && slot <= PS_CNT_ZP) || slot == PS_DROPPED; }
 
 // ------------------------------------------------------------------------------------------------
 // geometry helpers
@@ -75,7 +83,7 @@ __device__ __forceinline__ int cell_coord(double x, double icsz, int n)
     return c;
 }
 
-__device__ __forceinline__ int local_cell(const StepParams& P, double x, double y, double z)
+__device__ __forceinline__ int local_cell(const StepParams& P, double x, double y, double z, int* layer = nullptr)
 {
     int gx = cell_coord(x, P.icsz[0], P.nc[0]);
     int cy = cell_coord(y, P.icsz[1], P.nc[1]);
@@ -83,6 +91,7 @@ __device__ __forceinline__ int local_cell(const StepParams& P, double x, double 
     int lx = gx - P.cx0;                 // window of x-layers held by this rank (periodic unwrap)
     if (lx >= P.nc[0]) lx -= P.nc[0];
     if (lx < 0) lx += P.nc[0];
+    if (layer) *layer = lx;
     return (lx * P.nc[1] + cy) * P.nc[2] + cz;
 }
 
@@ -217,16 +226,33 @@ struct Counts
     int32_t pad;
 };
 
+__device__ __forceinline__ int wave_append(bool flag, int32_t* counter)
+{   // position of this lane's element in a shared output list (one atomic per wave), -1 if the lane has nothing to append
+    const unsigned long long mask = __ballot(flag);
+    if (mask == 0ULL) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader, kWave);
+    const unsigned long long below = mask & ((1ULL << lane) - 1ULL);
+    return flag ? base + __popcll(below) : -1;
+}
+
+// In slab mode the same kernel also packs this rank's message to each x-neighbour (slab.hip.h describes the protocol):
+// emigrants (full state) and the atoms of the hw boundary layers (position, type, id, radius), appended with one atomic per
+// wave and category.
 template <bool INTEGRATE>
-__global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTable S, AtomArrays A, const Counts* __restrict__ cnt,
+__global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTable S, AtomArrays A, Counts* __restrict__ cnt,
                                                            int32_t* __restrict__ cellOf, int32_t* __restrict__ slotOf,
-                                                           int32_t* __restrict__ cellCount, double* __restrict__ partials, int maxBlocks)
+                                                           int32_t* __restrict__ cellCount, double* __restrict__ partials, int maxBlocks,
+                                                           MsgLayout lay, char* __restrict__ sendLeft, char* __restrict__ sendRight)
 {
     __shared__ double scratch[kBlock / kWave];
     const int begin = cnt->ownedBegin, end = cnt->ownedEnd;
     const int i = begin + blockIdx.x * kBlock + threadIdx.x;
     double eField = 0.0, mom[6] = {0, 0, 0, 0, 0, 0}, cross[6] = {0, 0, 0, 0, 0, 0};
-    int anyCross = 0, myCell = 0;
+    int anyCross = 0, myCell = 0, myLayer = 0;
     if (i < end)
     {
         const int t = A.type[i];
@@ -249,8 +275,42 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
             A.x[i] = x; A.y[i] = y; A.z[i] = z;
             eField = S.charge[t] * (x * P.E[0] + y * P.E[1] + z * P.E[2]);      // integrators.cpp:374 / cuMDfunc.cu:476
         }
-        myCell = local_cell(P, x, y, z);
+        int lx;
+        myCell = local_cell(P, x, y, z, &lx);
         cellOf[i] = myCell;
+        myLayer = lx;
+    }
+    if (P.nranks > 1)
+    {
+        const bool live = i < end;
+        const int hw = P.hw[0], lx = myLayer;
+        const bool migL = live && lx < hw, migR = live && lx >= P.ncxLocal - hw;
+        const bool haloL = live && lx >= hw && lx < 2 * hw, haloR = live && lx >= P.ncxLocal - 2 * hw && lx < P.ncxLocal - hw;
+        SendHeader* hL = (SendHeader*)sendLeft;
+        SendHeader* hR = (SendHeader*)sendRight;
+        const int pML = wave_append(migL, &hL->nMig), pMR = wave_append(migR, &hR->nMig);
+        const int pHL = wave_append(haloL, &hL->nHalo), pHR = wave_append(haloR, &hR->nHalo);
+        if (migL || migR)
+        {
+            const int p = migL ? pML : pMR;
+            if (p >= lay.migCap) cnt->overflow = 1;
+            else
+            {
+                MigRec* r = (MigRec*)((migL ? sendLeft : sendRight) + lay.mig_offset()) + p;
+                r->x = A.x[i]; r->y = A.y[i]; r->z = A.z[i]; r->vx = A.vx[i]; r->vy = A.vy[i]; r->vz = A.vz[i];
+                r->U = A.U[i]; r->rad = A.rad[i]; r->type = A.type[i]; r->id = A.id[i]; r->pad0 = 0; r->pad1 = 0;
+            }
+        }
+        if (haloL || haloR)
+        {
+            const int p = haloL ? pHL : pHR;
+            if (p >= lay.haloCap) cnt->overflow = 1;
+            else
+            {
+                HaloRec* r = (HaloRec*)((haloL ? sendLeft : sendRight) + lay.halo_offset()) + p;
+                r->x = A.x[i]; r->y = A.y[i]; r->z = A.z[i]; r->rad = A.rad[i]; r->type = A.type[i]; r->id = A.id[i];
+            }
+        }
     }
     {
         // histogram with one atomic per RUN of equal cells inside the wave: the arrays are still in the previous
@@ -274,13 +334,12 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
         double s = 0.0;
         if (P.E[0] != 0.0 || P.E[1] != 0.0 || P.E[2] != 0.0) s = block_sum(eField, scratch);
         if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EFIELD, s);
-        const int blockCross = __syncthreads_or(anyCross);     // wall crossings are rare: skip 12 reductions otherwise
-        for (int k = 0; k < 6; k++)
-        {
-            double a = 0.0, b = 0.0;
-            if (blockCross) { a = block_sum(mom[k], scratch); b = block_sum(cross[k], scratch); }
-            if (threadIdx.x == 0) { put_partial(partials, maxBlocks, PS_MOM_XN + k, a); put_partial(partials, maxBlocks, PS_CNT_XN + k, b); }
-        }
+        if (__syncthreads_or(anyCross))                         // wall crossings are rare: skip 12 reductions otherwise
+            for (int k = 0; k < 6; k++)
+            {
+                const double a = block_sum(mom[k], scratch), b = block_sum(cross[k], scratch);
+                if (threadIdx.x == 0 && b != 0.0) { add_partial(partials, maxBlocks, PS_MOM_XN + k, a); add_partial(partials, maxBlocks, PS_CNT_XN + k, b); }
+            }
     }
 }
 
@@ -454,7 +513,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_atom(StepParams P, SpecTable S,
     double s;
     s = block_sum(acc.eV, scratch); if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EVDW, s);
     s = block_sum(acc.eC, scratch); if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_ECOUL, s);
-    s = block_sum(acc.dropped, scratch); if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_DROPPED, s);
+    s = block_sum(acc.dropped, scratch); if (threadIdx.x == 0 && s != 0.0) add_partial(partials, maxBlocks, PS_DROPPED, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -462,10 +521,12 @@ __global__ __launch_bounds__(kBlock) void k_pair_atom(StepParams P, SpecTable S,
 //      integrators.cpp:486-531).  Also clears the cell histogram for the next step (clear_clist).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_integrate2(StepParams P, SpecTable S, AtomArrays A, const Counts* __restrict__ cnt,
-                                                       int32_t* __restrict__ cellCount, int nCell, double* __restrict__ partials, int maxBlocks)
+                                                       int32_t* __restrict__ cellCount, int nCell, double* __restrict__ partials, int maxBlocks,
+                                                       DevStats* st)
 {
     __shared__ double scratch[kBlock / kWave];
     const int gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid == 0) st->step += 1;     // the step in flight gets its 1-based number (main.cpp:92); no other thread of this launch reads it
     for (int c = gid; c < nCell; c += gridDim.x * kBlock) cellCount[c] = 0;
     const int i = cnt->ownedBegin + gid;
     double kin = 0.0;
@@ -504,7 +565,7 @@ __global__ __launch_bounds__(1024) void k_reduce_kin(StepParams P, const double*
 __global__ void k_scale_decision(StepParams P, DevStats* st, const double* __restrict__ ekGlobal)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const long long iStep = st->step + 1;                         // 1-based index of the step in flight (main.cpp:92)
+    const long long iStep = st->step;                             // 1-based index of the step in flight (set by k_integrate2)
     const double ek = ekGlobal[0];
     double k = 1.0;
     if (P.nEq > 0 && iStep <= P.nEq && P.freqEq > 0 && (iStep % P.freqEq) == 0 && ek != 0.0)
@@ -553,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void k_post(StepParams P, SpecTable S, Atom
         if (k != 1.0) { vx *= k; vy *= k; vz *= k; }
         if (P.tstat == 2)
         {
-            const uint64_t step = (uint64_t)(st->step + 1);
+            const uint64_t step = (uint64_t)st->step;
             const uint64_t id = (uint64_t)A.id[i];
             const int tp = A.type[i];
             const double m = S.mass[tp];
@@ -616,7 +677,7 @@ __global__ __launch_bounds__(kBlock) void k_post(StepParams P, SpecTable S, Atom
 // partials, k_finalize adds the kCollectParts sub-totals in order
 constexpr int kCollectParts = 16;
 
-__global__ __launch_bounds__(256) void k_collect(const double* __restrict__ partials, int maxBlocks, int nBlocksAtoms, int nBlocksPair,
+__global__ __launch_bounds__(256) void k_collect(double* __restrict__ partials, int maxBlocks, int nBlocksAtoms, int nBlocksPair,
                                                  double* __restrict__ stage, unsigned slotMask)
 {
     __shared__ double scratch[4];
@@ -627,7 +688,13 @@ __global__ __launch_bounds__(256) void k_collect(const double* __restrict__ part
         const int nb = (slot == PS_EVDW || slot == PS_ECOUL || slot == PS_DROPPED) ? nBlocksPair : nBlocksAtoms;
         const int per = (nb + kCollectParts - 1) / kCollectParts;
         const int b0 = part * per, b1 = min(nb, b0 + per);
-        for (int b = b0 + threadIdx.x; b < b1; b += blockDim.x) v += partials[(size_t)slot * maxBlocks + b];
+        const bool clear = slot_accumulates(slot);
+        for (int b = b0 + threadIdx.x; b < b1; b += blockDim.x)
+        {
+            const size_t idx = (size_t)slot * maxBlocks + b;
+            v += partials[idx];
+            if (clear) partials[idx] = 0.0;
+        }
     }
     v = block_sum(v, scratch);
     if (threadIdx.x == 0) stage[slot * kCollectParts + part] = v;
@@ -635,7 +702,7 @@ __global__ __launch_bounds__(256) void k_collect(const double* __restrict__ part
 
 // reset_quantities + calc_quantities (cuMDfunc.cu:270, main.cu:121-194 ; serial calc_chars integrators.cpp:63-73).
 // Works on this rank's sums; the cross-rank sum is taken when the host asks for statistics (Engine::get_stats).
-__global__ void k_finalize(StepParams P, DevStats* st, const double* __restrict__ stage, unsigned slotMask, int advance)
+__global__ void k_finalize(StepParams P, DevStats* st, const double* __restrict__ stage, unsigned slotMask)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (int slot = 0; slot < PS_COUNT; slot++)
@@ -660,7 +727,6 @@ __global__ void k_finalize(StepParams P, DevStats* st, const double* __restrict_
     st->temperature = 2.0 * st->engKin * P.revDegFree * P.rkB;
     st->engPot = st->engCoul + st->engVdW;
     st->engTot = st->engElecField + st->engVdW + st->engCoul + st->engKin;
-    if (advance) st->step += 1;
 }
 
 }  // namespace aztot

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
     {
         put_partial(partials, maxBlocks, PS_EVDW, eV);
         put_partial(partials, maxBlocks, PS_ECOUL, eC);
-        put_partial(partials, maxBlocks, PS_DROPPED, dropped);
+        if (dropped != 0.0) add_partial(partials, maxBlocks, PS_DROPPED, dropped);
     }
 }
 

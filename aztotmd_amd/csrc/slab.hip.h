@@ -6,7 +6,7 @@
 // * migrants: atoms this rank integrated whose new cell layer belongs to the neighbour (full state);
 //   the sender KEEPS them as ghosts (they sit exactly in its ghost layer), so nothing comes back;
 // * halo: this rank's owned atoms in its hw boundary layers (position, type, id, radius only).
-// Packing uses wave64 ballot + popcount prefix with one atomic per wave and category; the receiver reads
+// Packing (inside k_integrate1_bin) uses wave64 ballot + popcount prefix with one atomic per wave and category; the receiver reads
 // the counts from the header on the device, so a step needs no host round trip.  Ghost coordinates stay
 // global: distances go through the same minimum-image arithmetic as on one GPU, and together with the
 // id-ordered cells this makes N-GPU forces bit-identical to 1-GPU forces.
@@ -16,61 +16,11 @@
 
 namespace aztot {
 
-__device__ __forceinline__ int wave_append(bool flag, int32_t* counter)
-{   // position of this lane's element in a shared output list, -1 if the lane has nothing to append
-    const unsigned long long mask = __ballot(flag);
-    if (mask == 0ULL) return -1;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
-    base = __shfl(base, leader, kWave);
-    const unsigned long long below = mask & ((1ULL << lane) - 1ULL);
-    return flag ? base + __popcll(below) : -1;
-}
-
-__global__ __launch_bounds__(kBlock) void k_pack(StepParams P, AtomArrays A, Counts* cnt, const int32_t* __restrict__ cellOf,
-                                                 MsgLayout lay, char* __restrict__ sendLeft, char* __restrict__ sendRight)
-{
-    const int i = cnt->ownedBegin + blockIdx.x * kBlock + threadIdx.x;
-    const bool live = i < cnt->ownedEnd;
-    const int plane = P.nc[1] * P.nc[2];
-    const int hw = P.hw[0];
-    int lx = hw;
-    if (live) lx = cellOf[i] / plane;
-    const bool migL = live && lx < hw, migR = live && lx >= P.ncxLocal - hw;
-    const bool haloL = live && lx >= hw && lx < 2 * hw, haloR = live && lx >= P.ncxLocal - 2 * hw && lx < P.ncxLocal - hw;
-    SendHeader* hL = (SendHeader*)sendLeft;
-    SendHeader* hR = (SendHeader*)sendRight;
-    const int pML = wave_append(migL, &hL->nMig), pMR = wave_append(migR, &hR->nMig);
-    const int pHL = wave_append(haloL, &hL->nHalo), pHR = wave_append(haloR, &hR->nHalo);
-    if (migL || migR)
-    {
-        const int p = migL ? pML : pMR;
-        if (p >= lay.migCap) cnt->overflow = 1;
-        else
-        {
-            MigRec* r = (MigRec*)((migL ? sendLeft : sendRight) + lay.mig_offset()) + p;
-            r->x = A.x[i]; r->y = A.y[i]; r->z = A.z[i]; r->vx = A.vx[i]; r->vy = A.vy[i]; r->vz = A.vz[i];
-            r->U = A.U[i]; r->rad = A.rad[i]; r->type = A.type[i]; r->id = A.id[i]; r->pad0 = 0; r->pad1 = 0;
-        }
-    }
-    if (haloL)
-    {
-        if (pHL >= lay.haloCap) cnt->overflow = 1;
-        else { HaloRec* r = (HaloRec*)(sendLeft + lay.halo_offset()) + pHL; r->x = A.x[i]; r->y = A.y[i]; r->z = A.z[i]; r->rad = A.rad[i]; r->type = A.type[i]; r->id = A.id[i]; }
-    }
-    if (haloR)
-    {
-        if (pHR >= lay.haloCap) cnt->overflow = 1;
-        else { HaloRec* r = (HaloRec*)(sendRight + lay.halo_offset()) + pHR; r->x = A.x[i]; r->y = A.y[i]; r->z = A.z[i]; r->rad = A.rad[i]; r->type = A.type[i]; r->id = A.id[i]; }
-    }
-}
-
 // append what the two neighbours sent behind the owned range and add it to the cell histogram
 __global__ __launch_bounds__(kBlock) void k_unpack(StepParams P, AtomArrays A, Counts* cnt, int capacity, MsgLayout lay,
                                                    const char* __restrict__ fromLeft, const char* __restrict__ fromRight,
-                                                   int32_t* __restrict__ cellOf, int32_t* __restrict__ slotOf, int32_t* __restrict__ cellCount)
+                                                   int32_t* __restrict__ cellOf, int32_t* __restrict__ slotOf, int32_t* __restrict__ cellCount,
+                                                   char* __restrict__ sendLeft, char* __restrict__ sendRight)
 {
     const SendHeader hL = *(const SendHeader*)fromLeft, hR = *(const SendHeader*)fromRight;
     const int nML = min(hL.nMig, lay.migCap), nHL = min(hL.nHalo, lay.haloCap);
@@ -80,6 +30,9 @@ __global__ __launch_bounds__(kBlock) void k_unpack(StepParams P, AtomArrays A, C
     int t = blockIdx.x * kBlock + threadIdx.x;
     if (t == 0)
     {
+        // the send buffers have travelled: clear their counters for the next step's packing
+        SendHeader z = {0, 0, 0, 0};
+        *(SendHeader*)sendLeft = z; *(SendHeader*)sendRight = z;
         if (base + total > capacity) cnt->overflow = 1;
         cnt->nRecv = min(total, max(capacity - base, 0));
     }

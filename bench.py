@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline sample (0: sized for ~15 s)")
     ap.add_argument("--debug", type=int, default=0, help="kernel ablation switches (results invalid)")
+    ap.add_argument("--emulate-ranks", type=int, default=0, help="measurement aid: time rank 0 of an N-rank slab run on one GPU (loopback halo)")
     ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels (enables hipGraph replay)")
     return ap.parse_args()
 
@@ -125,12 +126,16 @@ def main():
         idb = [api.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(idb, src=0)
         slab = {"rank": rank, "nranks": world, "rccl_id": idb[0]}
+    if a.emulate_ranks > 1 and world == 1:
+        slab = {"rank": a.emulate_ranks // 2, "nranks": a.emulate_ranks, "loopback": True}
     transport = "single GPU"
     try:
         eng = api.Engine(model, device=local_rank, initial_forces=1, pair_variant=a.pair_variant, cell_size=a.cell_size,
                          use_graph=1, profile=0, slab=slab, debug=a.debug)
         if world > 1:
             transport = "RCCL send/recv over xGMI"
+        if a.emulate_ranks > 1:
+            transport = "LOOPBACK EMULATION of one rank of %d - not a result" % a.emulate_ranks
         ok = 1
     except api.AztotError as ex:
         if world == 1:
