@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 STAT_FIELDS = ("step", "time", "engTot", "engKin", "engVdW", "engCoul", "engElecField", "engTemp", "engPot", "temperature",
-               "posMom", "negMom", "posCross", "negCross", "pressure", "pairs_dropped", "n_cells")
+               "posMom", "negMom", "posCross", "negCross", "pressure", "pairs_dropped", "n_cells", "nose_chit", "nose_conint")
 
 
 class AztotError(RuntimeError):
@@ -55,7 +55,8 @@ class _Stats(C.Structure):
     _fields_ = [("step", C.c_int64), ("time", C.c_double), ("engTot", C.c_double), ("engKin", C.c_double), ("engVdW", C.c_double),
                 ("engCoul", C.c_double), ("engElecField", C.c_double), ("engTemp", C.c_double), ("engPot", C.c_double),
                 ("temperature", C.c_double), ("posMom", C.c_double * 3), ("negMom", C.c_double * 3), ("posCross", C.c_int64 * 3),
-                ("negCross", C.c_int64 * 3), ("pressure", C.c_double), ("pairs_dropped", C.c_int64), ("n_cells", C.c_int64)]
+                ("negCross", C.c_int64 * 3), ("pressure", C.c_double), ("pairs_dropped", C.c_int64), ("n_cells", C.c_int64),
+                ("nose_chit", C.c_double), ("nose_conint", C.c_double)]
 
 
 class _State(C.Structure):
@@ -177,6 +178,7 @@ class Model:
         c = s.control
         c.timestep, c.nstep, c.nequil, c.eqfreq = case["dt"], int(case.get("nsteps", 0)), int(case.get("nEq", 0)), int(case.get("freqEq", 1))
         c.temperature, c.tstat_type = float(case.get("T", 0.0)), int(case.get("tstat_type", 0))
+        c.tstat_tau = float(case.get("tau", 0.0))
         c.elec_type, c.r_real, c.alpha = int(case.get("elec_type", 0)), float(case.get("rReal", 0.0)), float(case.get("alpha", 0.0))
         c.init_vel = 0
         c.elecfield = (C.c_double * 3)(case.get("Ux", 0.0), case.get("Uy", 0.0), case.get("Uz", 0.0))

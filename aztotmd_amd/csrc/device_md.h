@@ -58,6 +58,7 @@ struct StepParams
     // thermostat
     int32_t tstat, nEq, freqEq, pad0;
     double tKin, revDegFree, rkB;
+    double rQmass, qMassTau2;     // Nose-Hoover: 1/(2 tKin tau^2), 2 tKin (sys_init.cpp:1107-1112)
     double revLight, radFrac, radThr, numPi;
     uint64_t seed;
     int32_t nAtGlobal, pad1;
@@ -82,7 +83,10 @@ struct DevStats
     double mom[6];                // Xn, Xp, Yn, Yp, Zn, Zp accumulated over the run (box.cpp:230-295)
     long long cross[6];
     long long dropped;
-    double vscale;                // equilibration velocity scale decided for the current step (1 = none)
+    double vscale;                // velocity scale decided for the END of the current step: equilibration x Nose-Hoover (1 = none)
+    double vscaleBegin;           // Nose-Hoover scale applied at the BEGINNING of the step (integrate1, integrators.cpp:305)
+    double ekSim;                 // the reference's sim->engKin as the thermostats see it (value left by the previous integrate2)
+    double chit, conint;          // Nose-Hoover friction and conserved-quantity integral (temperature.h:24-25)
     double local[PS_COUNT];       // this rank's per-step sums before the cross-rank reduction
 };
 

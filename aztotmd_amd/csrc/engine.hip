@@ -139,6 +139,7 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
     P_.elec_type = m.elec_type; P_.alpha = m.alpha; P_.el_scale = m.el_scale; P_.el_scale2 = m.el_scale2; P_.daipi2 = m.daipi2;
     P_.rReal = m.rReal; P_.fcoul = units::Fcoul_scale; P_.sqrtpi = std::sqrt(units::pi);
     P_.tstat = m.tstat_type; P_.nEq = m.nEq; P_.freqEq = m.freqEq; P_.tKin = m.tKin; P_.revDegFree = m.revDegFree; P_.rkB = 1.0 / units::kB;
+    if (m.tstat_type == AZTOT_TSTAT_NOSE) { P_.rQmass = 0.5 / m.tKin / m.tau / m.tau; P_.qMassTau2 = 2 * m.tKin; }
     P_.revLight = 3.33567e-5;   // cuTemp.cu:225 (SURVEY C-19: 100x the physical 1/c, kept for behavioural parity)
     P_.radFrac = 0.9;           // cuTemp.cu:639
     P_.radThr = 1e-4;           // cuTemp.cu:747
@@ -220,7 +221,8 @@ void Engine::allocate()
     {
         DevStats zero;
         std::memset(&zero, 0, sizeof(zero));
-        zero.vscale = 1.0;          // "no equilibration scaling"; only k_scale_decision ever changes it
+        zero.vscale = 1.0;          // "no scaling"; only k_scale_decision ever changes it
+        zero.vscaleBegin = 1.0;
         HIP_CHECK(hipMemcpy(dStats_, &zero, sizeof(DevStats), hipMemcpyHostToDevice));
     }
     dCounts_ = (Counts*)alloc(sizeof(Counts));
@@ -334,14 +336,14 @@ void Engine::sort_and_forces(bool integrate_first)
     if (integrate_first)
         timed("integrate1_bin", [&] {
             hipLaunchKernelGGL(k_integrate1_bin<true>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
-                               dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1]);
+                               dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1], dStats_);
         });
     else
     {
         HIP_CHECK(hipMemsetAsync(dCellCount_, 0, sizeof(int32_t) * (size_t)(nCellAlloc_ + 1), stream_));
         timed("bin", [&] {
             hipLaunchKernelGGL(k_integrate1_bin<false>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
-                               dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1]);
+                               dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1], dStats_);
         });
     }
     if (nranks_ > 1) exchange_halo();
@@ -388,12 +390,13 @@ void Engine::forces()
 void Engine::launch_step_kernels()
 {
     const int gridAtoms = div_up(capacity_, kBlock);
+    if (P_.tstat == AZTOT_TSTAT_NOSE) timed("nose_begin", [&] { hipLaunchKernelGGL(k_nose_begin, dim3(1), dim3(64), 0, stream_, P_, dStats_); });
     sort_and_forces(true);
     timed("integrate2", [&] {
         hipLaunchKernelGGL(k_integrate2, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal, dPartials_,
                            maxBlocks_, dStats_);
     });
-    const bool equil = P_.nEq > 0;
+    const bool equil = P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE;     // the step needs the all-atom kinetic energy on the device
     if (equil)
     {
         timed("reduce_kin", [&] {
@@ -421,7 +424,7 @@ void Engine::launch_step_kernels()
 void Engine::finish_steps()
 {
     unsigned mask = (1u << PS_COUNT) - 1u;
-    if (P_.nEq > 0) mask &= ~(1u << PS_EKIN);            // k_reduce_kin / k_scale_decision own engKin while equilibrating
+    if (P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE) mask &= ~(1u << PS_EKIN);   // k_reduce_kin / k_scale_decision own engKin then
     if (!(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_RADI)) mask &= ~(1u << PS_ETEMP);
     collect_and_finalize(mask);
 }
@@ -485,6 +488,7 @@ void Engine::get_stats(aztot_stats& out)
     out.posCross[1] = (int64_t)v[14]; out.negCross[2] = (int64_t)v[15]; out.posCross[2] = (int64_t)v[16];
     out.pairs_dropped = (int64_t)v[17];
     out.n_cells = (int64_t)P_.nc[0] * P_.nc[1] * P_.nc[2];
+    out.nose_chit = s.chit; out.nose_conint = s.conint;
     // pressure from the wall momentum over the window since the previous evaluation (main.cpp:143-163)
     if (s.step - lastPresStep_ >= std::max(1, model_.stat))
     {

@@ -246,7 +246,8 @@ template <bool INTEGRATE>
 __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTable S, AtomArrays A, Counts* __restrict__ cnt,
                                                            int32_t* __restrict__ cellOf, int32_t* __restrict__ slotOf,
                                                            int32_t* __restrict__ cellCount, double* __restrict__ partials, int maxBlocks,
-                                                           MsgLayout lay, char* __restrict__ sendLeft, char* __restrict__ sendRight)
+                                                           MsgLayout lay, char* __restrict__ sendLeft, char* __restrict__ sendRight,
+                                                           const DevStats* __restrict__ st)
 {
     __shared__ double scratch[kBlock / kWave];
     const int begin = cnt->ownedBegin, end = cnt->ownedEnd;
@@ -260,9 +261,11 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
         if (INTEGRATE)
         {
             const double rM = S.rMhdt[t], m = S.mass[t];
-            double vx = A.vx[i] + rM * A.fx[i];
-            double vy = A.vy[i] + rM * A.fy[i];
-            double vz = A.vz[i] + rM * A.fz[i];
+            double vx = A.vx[i], vy = A.vy[i], vz = A.vz[i];
+            if (P.tstat == 1) { const double sc = st->vscaleBegin; vx *= sc; vy *= sc; vz *= sc; }   // tstat_nose at integrators.cpp:305-306
+            vx += rM * A.fx[i];
+            vy += rM * A.fy[i];
+            vz += rM * A.fz[i];
             if (!S.frozen[t]) { x += vx * P.dt; y += vy * P.dt; z += vz * P.dt; }
             int c;
             c = wrap_coord(x, P.L[0], P.invL[0]);
@@ -562,18 +565,51 @@ __global__ __launch_bounds__(1024) void k_reduce_kin(StepParams P, const double*
     if (threadIdx.x == 0) { st->local[PS_EKIN] = ek; ekOut[0] = ek; }
 }
 
+// tstat_nose (temperature.cpp:339-360) on the scalars; the per-atom velocity scaling happens in the next per-atom kernel
+__device__ __forceinline__ double nose_update(const StepParams& P, DevStats* st, double ek, double* kinEout)
+{
+    st->chit += P.dt * (ek - P.tKin) * P.rQmass;
+    const double scale = 1 - P.dt * st->chit;
+    const double kinE = ek * scale * scale;
+    st->conint += P.dt * st->chit * P.qMassTau2;
+    st->chit += P.dt * (kinE - P.tKin) * P.rQmass;
+    *kinEout = kinE;
+    return scale;
+}
+
+// beginning of a step (integrate1 / integrate1_clst, integrators.cpp:305,340): Nose-Hoover scales the velocities with the kinetic
+// energy the previous integrate2 left in sim->engKin; the energy it returns is discarded there
+__global__ void k_nose_begin(StepParams P, DevStats* st)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double unused;
+    st->vscaleBegin = nose_update(P, st, st->ekSim, &unused);
+}
+
+// end of a step (integrate2, integrators.cpp:507-529): equilibration rescaling first, then Nose-Hoover
 __global__ void k_scale_decision(StepParams P, DevStats* st, const double* __restrict__ ekGlobal)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long iStep = st->step;                             // 1-based index of the step in flight (set by k_integrate2)
-    const double ek = ekGlobal[0];
+    double ek = ekGlobal[0];
     double k = 1.0;
+    bool changed = false;
     if (P.nEq > 0 && iStep <= P.nEq && P.freqEq > 0 && (iStep % P.freqEq) == 0 && ek != 0.0)
     {
         const double c = (P.tstat == 2) ? 0.25 : 1.0;             // cuTemp.cu:90-94
         k = sqrt(c * P.tKin / ek);
-        st->local[PS_EKIN] = P.tKin / (double)P.nranks;           // engKin := tKin (integrators.cpp:521, cuTemp.cu:112)
+        ek = P.tKin;                                              // engKin := tKin (integrators.cpp:521, cuTemp.cu:112)
+        changed = true;
     }
+    if (P.tstat == 1)
+    {
+        double kinE;
+        k *= nose_update(P, st, ek, &kinE);
+        ek = kinE;
+        changed = true;
+    }
+    if (changed) st->local[PS_EKIN] = ek / (double)P.nranks;
+    st->ekSim = ek;
     st->vscale = k;
 }
 

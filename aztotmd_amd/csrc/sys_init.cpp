@@ -427,8 +427,7 @@ void finish_model(Model& m, uint64_t seed)
     // prepare_elec: elec.cpp:371-406 (Fennell constants; k-space Ewald is out of scope)
     if (m.elec_type == AZTOT_ELEC_EWALD)
         fail("out of scope: 'elec pme' (reciprocal-space Ewald) is not part of the accelerated hot path (short-range electrostatics only)");
-    if (m.tstat_type == AZTOT_TSTAT_NOSE)
-        fail("out of scope: Nose-Hoover thermostat is not part of the accelerated hot path (radiative thermostat / none)");
+    if (m.tstat_type == AZTOT_TSTAT_NOSE && !(m.tau > 0)) fail("ERROR[405] 'nose' needs a positive relaxation time");
     if (m.elec_type == AZTOT_ELEC_FENNEL)
     {
         const double sqrtpi = std::sqrt(units::pi);

@@ -116,7 +116,8 @@ def write_input_files(case, directory, stat=200):
         f.write("nequil %d\n" % case.get("nEq", 0))
         f.write("eqfreq %d\n" % case.get("freqEq", 1))
         ts = TSTAT_NAMES[case.get("tstat_type", 0)]
-        f.write("temperature %r\t%s%s\n" % (float(case.get("T", 0.0)), ts, "\t0.2" if ts == "radi" else ""))
+        extra = "\t0.2" if ts == "radi" else ("\t%r" % float(case.get("tau", 0.0)) if ts == "nose" else "")
+        f.write("temperature %r\t%s%s\n" % (float(case.get("T", 0.0)), ts, extra))
         f.write("init_vel\tzero\n")
         f.write("permittivity 1.0\n")
         f.write("cell_list\t%r\n" % float(case.get("cell_list", 8.5)))

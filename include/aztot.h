@@ -114,6 +114,7 @@ typedef struct
     double pressure;             /* from wall momentum over the last 'stat' window (main.cpp:146-152) */
     int64_t pairs_dropped;       /* pairs skipped by the |f|^2 > 1e10 rule (integrators.cpp:170) */
     int64_t n_cells;
+    double nose_chit, nose_conint;  /* Nose-Hoover friction and conserved-quantity integral (temperature.h:24-25) */
 } aztot_stats;
 
 /* host copy of the per-atom state, fp64 SoA, in ORIGINAL atom order (id order); any pointer may be NULL */

@@ -70,6 +70,7 @@ typedef struct
     double Ux, Uy, Uz;
     /* thermostat + control */
     int tstat_type; double Temp, tKin; int degFree; int nEq, freqEq;
+    double tau, chit, conint, rQmass, qMassTau2;         /* Nose-Hoover: temperature.h:24-31 */
     int use_clist;                                       /* control.txt 'cell_list' present */
     /* linked cells: Sim fields dataStruct.h:88-99 */
     int nHead, cnX, cnY, cnZ, cnYZ; double clX, clY, clZ;
@@ -182,6 +183,8 @@ void orc_set_elec(orc_sys *s, int type, double rReal, double alpha)
 {
     s->elec_type = type; s->rReal = rReal; s->alpha = alpha;
 }
+
+void orc_set_nose(orc_sys *s, double tau) { s->tau = tau; }
 
 void orc_set_control(orc_sys *s, double dt, double T, int tstat_type, int nEq, int freqEq, int use_clist,
                      double Ux, double Uy, double Uz, uint64_t seed)
@@ -310,6 +313,12 @@ int orc_prepare(orc_sys *s)
     s->r2Max = s->rMax * s->rMax;
     s->degFree = 3 * s->N; if (s->tstat_type) s->degFree--;                             /* :1099-1103 */
     s->tKin = 0.5 * s->Temp * c_kB() * s->degFree;                                      /* :1106 */
+    if (s->tstat_type == TSTAT_NOSE)
+    {   /* sys_init.cpp:1107-1112 ; read_tstat temperature.cpp:103-111 */
+        s->rQmass = 0.5 / s->tKin / s->tau / s->tau;
+        s->qMassTau2 = 2 * s->tKin;
+        s->chit = 0.0; s->conint = 0.0;
+    }
     if (s->use_clist) init_clist(s, s->rMax);                                           /* :1130-1133 */
     if (s->tstat_type == TSTAT_RADI)
     {   /* read_tstat temperature.cpp:113-245 ; init_cuda_tstat cuTemp.cu:25-60 */
@@ -546,9 +555,21 @@ static void build_clist(orc_sys *s)
     }
 }
 
+static double tstat_nose(orc_sys *s)
+{   /* tstat_nose: temperature.cpp:339-360 */
+    s->chit += s->dt * (s->engKin - s->tKin) * s->rQmass;
+    double scale = 1 - s->dt * s->chit;
+    for (int i = 0; i < s->N; i++) { s->vx[i] *= scale; s->vy[i] *= scale; s->vz[i] *= scale; }
+    double kinE = s->engKin * scale * scale;
+    s->conint += s->dt * s->chit * s->qMassTau2;
+    s->chit += s->dt * (kinE - s->tKin) * s->rQmass;
+    return kinE;
+}
+
 static void integrate1(orc_sys *s)
 {   /* integrate1 / integrate1_clst: integrators.cpp:292-376 ; frozen species as cuMDfunc.cu:415-420 */
     double tSt = s->dt;
+    if (s->tstat_type == TSTAT_NOSE) tstat_nose(s);        /* :305-306 / :340-341 - the returned energy is discarded there */
     if (s->nHead) for (int c = 0; c < s->nHead; c++) s->chead[c] = -1;
     for (int i = 0; i < s->N; i++)
     {
@@ -585,6 +606,7 @@ static void integrate2(orc_sys *s, int tScale)
         for (int i = 0; i < s->N; i++) { s->vx[i] *= k; s->vy[i] *= k; s->vz[i] *= k; }
         s->engKin = s->tKin;
     }
+    if (s->tstat_type == TSTAT_NOSE) s->engKin = tstat_nose(s);        /* integrators.cpp:525-529 */
 }
 
 static void calc_chars(orc_sys *s)
@@ -714,12 +736,13 @@ void orc_set_thermo(orc_sys *s, const double *U, const double *rad)
 { size_t nb = 8 * (size_t)s->N; if (U) memcpy(s->U, U, nb); if (rad) memcpy(s->rad, rad, nb); }
 const double *orc_photons(const orc_sys *s) { return s->photons; }
 
-/* out[0..15]: engVdW, engElec3, engKin, engTot, engElecField, engTemp, Temp, mom[6], nDropped, iStep, tKin */
+/* out[0..17]: engVdW, engElec3, engKin, engTot, engElecField, engTemp, Temp, mom[6], nDropped, iStep, tKin */
 void orc_get_stats(const orc_sys *s, double *out)
 {
     out[0] = s->engVdW; out[1] = s->engElec3; out[2] = s->engKin; out[3] = s->engTot; out[4] = s->engElecField;
     out[5] = s->engTemp; out[6] = s->TempNow;
     for (int k = 0; k < 6; k++) out[7 + k] = s->mom[k];
     out[13] = (double)s->nDropped; out[14] = (double)s->iStep; out[15] = s->tKin;
+    out[16] = s->chit; out[17] = s->conint;
 }
 void orc_get_cross(const orc_sys *s, long long *out) { for (int k = 0; k < 6; k++) out[k] = s->cross[k]; }

@@ -10,7 +10,7 @@ Layout (little endian):
   i32 elec_type ; f64 rReal, alpha
   i32 use_clist, center_box, init_forces
   i32 nEq, freqEq ; f64 T ; i32 tstat_type
-  f64 Ux
+  f64 Ux ; f64 tau (Nose-Hoover relaxation time)
   i32 ndump ; i32 dump_steps[ndump]
   nSpec x (f64 mass_amu, f64 charge)
   nVdw  x (i32 a, i32 b, i32 type, f64 rc, f64 p[5])
@@ -34,7 +34,7 @@ def write_case(path, case):
     dump = list(case.get("dump", [0]))
     with open(path, "wb") as f:
         f.write(b"AZTC")
-        f.write(struct.pack("<i", 1))
+        f.write(struct.pack("<i", 2))
         f.write(struct.pack("<iii", N, len(species), len(vdw)))
         f.write(struct.pack("<ddd", *case["box"]))
         f.write(struct.pack("<d", case["dt"]))
@@ -42,7 +42,7 @@ def write_case(path, case):
         f.write(struct.pack("<idd", case.get("elec_type", 0), case.get("rReal", 0.0), case.get("alpha", 0.0)))
         f.write(struct.pack("<iii", case.get("use_clist", 1), case.get("center_box", 0), case.get("init_forces", 1)))
         f.write(struct.pack("<iidi", case.get("nEq", 0), case.get("freqEq", 1), case.get("T", 0.0), case.get("tstat_type", 0)))
-        f.write(struct.pack("<d", case.get("Ux", 0.0)))
+        f.write(struct.pack("<dd", case.get("Ux", 0.0), case.get("tau", 0.0)))
         f.write(struct.pack("<i", len(dump)))
         f.write(struct.pack("<%di" % len(dump), *dump))
         for m, q in species:

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 STAT_FIELDS = ("engVdW", "engElec3", "engKin", "engTot", "engElecField", "engTemp", "Temp",
-               "momXn", "momXp", "momYn", "momYp", "momZn", "momZp", "nDropped", "iStep", "tKin")
+               "momXn", "momXp", "momYn", "momYp", "momZn", "momZp", "nDropped", "iStep", "tKin", "chit", "conint")
 
 
 def build(force=False):
@@ -49,6 +49,7 @@ def lib():
         L.orc_set_control.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, C.c_uint64]
         L.orc_prepare.argtypes = [C.c_void_p]
+        L.orc_set_nose.argtypes = [C.c_void_p, C.c_double]
         L.orc_center_box.argtypes = [C.c_void_p]
         L.orc_forces.argtypes = [C.c_void_p, C.c_int]
         L.orc_step.argtypes = [C.c_void_p, C.c_int]
@@ -115,6 +116,7 @@ class Oracle:
         L.orc_set_control(self.h, case["dt"], case.get("T", 0.0), case.get("tstat_type", 0), case.get("nEq", 0),
                           case.get("freqEq", 1), case.get("use_clist", 1), case.get("Ux", 0.0), case.get("Uy", 0.0),
                           case.get("Uz", 0.0), case.get("seed", 12345))
+        L.orc_set_nose(self.h, case.get("tau", 0.0))
         L.orc_prepare(self.h)
         if case.get("center_box", 0):
             L.orc_center_box(self.h)
@@ -142,7 +144,7 @@ class Oracle:
         return out
 
     def stats(self):
-        s = np.empty(16)
+        s = np.empty(18)
         self.L.orc_get_stats(self.h, _dp(s))
         d = dict(zip(STAT_FIELDS, s.tolist()))
         cr = (C.c_longlong * 6)()

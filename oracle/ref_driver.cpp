@@ -2,7 +2,7 @@
 //
 // ref_driver: a small harness of OUR OWN that is linked against the reference's own
 // serial-path translation units, compiled where they lie under /root/reference/src
-// (box.cpp, vdw.cpp, elec.cpp, cell_list.cpp, integrators.cpp - see oracle/Makefile).
+// (box.cpp, vdw.cpp, elec.cpp, cell_list.cpp, integrators.cpp, temperature.cpp - see oracle/Makefile).
 // No reference source is copied here; this file only *calls* the reference through the
 // declarations in its headers (-I/root/reference/src).
 //
@@ -52,7 +52,7 @@ int main(int argc, char** argv)
     if (!f) { perror(argv[1]); return 2; }
     char magic[4]; rd(f, magic, 4);
     if (memcmp(magic, "AZTC", 4) != 0) { fprintf(stderr, "bad magic\n"); return 2; }
-    int version = rd_i(f); (void)version;
+    int version = rd_i(f);
     int N = rd_i(f), nSpec = rd_i(f), nVdw = rd_i(f);
     double L[3]; rd(f, L, 24);
     double dt = rd_d(f);
@@ -61,6 +61,7 @@ int main(int argc, char** argv)
     int use_clist = rd_i(f), do_center = rd_i(f), init_forces = rd_i(f);
     int nEq = rd_i(f), freqEq = rd_i(f); double T = rd_d(f); int tstat_type = rd_i(f);
     double Ux = rd_d(f);
+    double tau = (version >= 2) ? rd_d(f) : 0.0;
     int ndump = rd_i(f);
     int* dump = (int*)malloc(sizeof(int) * (ndump + 1));
     for (int i = 0; i < ndump; i++) dump[i] = rd_i(f);
@@ -165,6 +166,13 @@ int main(int argc, char** argv)
     sim->degFree = 3 * N - 0; if (tstat->type) sim->degFree--;
     sim->revDegFree = (double)(1.0 / sim->degFree);
     tstat->tKin = 0.5 * sim->tTemp * kB * sim->degFree;
+    if (tstat->type == tpTermNose)
+    {   // read_tstat temperature.cpp:103-111 ; init_md sys_init.cpp:1107-1112
+        tstat->tau = tau; tstat->chit = 0.0; tstat->conint = 0.0;
+        tstat->qMass = 2 * tstat->tKin * tstat->tau * tstat->tau;
+        tstat->rQmass = 0.5 / tstat->tKin / tstat->tau / tstat->tau;
+        tstat->qMassTau2 = 2 * tstat->tKin;
+    }
 
     // ---- init_serial (sys_init.cpp:1122-1187) ----
     sim->nHead = 0;

@@ -105,3 +105,7 @@ if __name__ == "__main__":
         c[k] = vel[k]
     save_run("F1_tscale", c, [0, 5, 20, 30], keep_full=[5, 30])
     save_run("F2_survey", survey_f2_case(), [0, 50], keep_full=[])
+    # Nose-Hoover (tstat_nose, temperature.cpp:339-360) with equilibration rescaling on top
+    c = inputs.lj_case((5, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5, T=120.0, vel_T=80.0)
+    c.update(tstat_type=1, tau=0.05, nEq=10, freqEq=5)
+    save_run("F1_nose", c, [0, 1, 10, 40], keep_full=[1, 40])

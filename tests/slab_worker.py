@@ -51,6 +51,9 @@ def main():
     if name == "thermo":
         case = inputs.lj_case((12, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5, T=298.0, tstat="radi", vel_T=150.0,
                               radii=[(2.73, 4.731, 0.2)], nEq=10, freqEq=5)
+    elif name == "nose":
+        case = inputs.lj_case((12, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5, T=120.0, vel_T=80.0)
+        case.update(tstat_type=1, tau=0.05, nEq=10, freqEq=5)
     elif name == "fennel":
         case = inputs.lj_case((14, 6, 6), a=5.26, seed=7, charges=(0.2, -0.2), elec="fenn", vel_T=400.0)
     elif name == "hot":

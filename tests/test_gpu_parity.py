@@ -118,6 +118,33 @@ def test_golden_equilibration_scaling():
     assert abs(st["engTot"] - ref["engTot"]) < 1e-11 * abs(ref["engTot"])
 
 
+def test_golden_nose_hoover():
+    """Nose-Hoover thermostat + equilibration rescaling against the reference binary's trajectory (tests/golden/F1_nose.npz)."""
+    z = np.load(os.path.join(G, "F1_nose.npz"))
+    case = inputs.lj_case((5, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5, T=120.0, vel_T=80.0)
+    case.update(tstat_type=1, tau=0.05, nEq=10, freqEq=5)
+    for k in ("vx", "x"):
+        assert np.array_equal(case[k], z["in_" + k])
+    e = engine(case)
+    done = 0
+    for st in (1, 10, 40):
+        e.step(st - done)
+        done = st
+        stt = e.stats()
+        ref = dict(zip(EKEYS, z["e_%d" % st].tolist()))
+        assert abs(stt["engKin"] - ref["engKin"]) < 1e-11 * abs(ref["engKin"]), (st, stt["engKin"], ref["engKin"])
+        assert abs(stt["engTot"] - ref["engTot"]) < 1e-11 * abs(ref["engTot"])
+        if ("x_%d" % st) in z:
+            s = e.state()
+            for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+                assert rel_err(s[k], z["%s_%d" % (k, st)]) < 1e-9, (st, k)
+    o = oracle.Oracle(case)
+    o.forces(0)
+    o.step(40)
+    assert abs(e.stats()["nose_chit"] - o.stats()["chit"]) < 1e-10 * abs(o.stats()["chit"])
+    assert abs(e.stats()["nose_conint"] - o.stats()["conint"]) < 1e-10 * abs(o.stats()["conint"])
+
+
 def test_wall_crossing_counters_and_field():
     """hot gas: atoms cross the periodic walls; wall momenta, crossing counts and field energy vs the oracle."""
     case = mixed_case("lnjs+fenn+field", vel_T=3000.0)
