@@ -115,22 +115,23 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
             m[w] = (nb > 0) ? (~miss << (32 - nb)) : 0u;
         }
         if (P.pad0 & 2) { acc.fx += (double)(m[0] ^ m[1] ^ m[2]); m[0] = m[1] = m[2] = 0u; }
-        const int k0 = rb * NS + slice;
-        while (__any((m[0] | m[1] | m[2]) != 0u))
+        // pass 2: every lane pops its own hits.  `cur` is the word being drained, `nxt`/`lst` the ones still waiting; when
+        // `cur` runs dry the next word slides in (selects, no branches), so a lane keeps busy as long as ANY of its three
+        // words has hits left - the wave loops max-over-lanes(hits per lane) times, not sum-over-words(max per word).
+        // The body is branch-free: lanes without a hit run on a dummy candidate and are masked out.
+        uint32_t cur = m[0], nxt = m[1], lst = m[2];
+        int kbase = rb * NS + slice;                       // tile index of bit 31 of `cur`
+        while (__any((cur | nxt | lst) != 0u))
         {
-            // pop the first remaining hit of this lane: word selection by two compares, then one clz.  The body is
-            // branch-free (lanes without a hit run on a dummy candidate and are masked out): a conditional body makes
-            // the compiler shuffle all accumulators through copies on every iteration.
-            const bool h0 = m[0] != 0u, h1 = m[1] != 0u;
-            const uint32_t mw = h0 ? m[0] : (h1 ? m[1] : m[2]);
-            const bool live = mw != 0u;
-            const int b = __clz(mw | 1u);
-            const uint32_t bit = live ? (0x80000000u >> b) : 0u;
-            const int woff = h0 ? 0 : (h1 ? 32 * NS : 64 * NS);
-            m[0] ^= h0 ? bit : 0u;
-            m[1] ^= (!h0 & h1) ? bit : 0u;
-            m[2] ^= (!h0 & !h1) ? bit : 0u;
-            const int k = live ? (k0 + woff + b * NS) : k0;
+            const bool dry = cur == 0u;
+            cur = dry ? nxt : cur;
+            nxt = dry ? lst : nxt;
+            lst = dry ? 0u : lst;
+            kbase += dry ? 32 * NS : 0;
+            const bool live = cur != 0u;
+            const int b = __clz(cur | 1u);
+            cur &= ~(0x80000000u >> b);                    // for a dry word this clears bit 0 of zero: harmless
+            const int k = live ? kbase + b * NS : T;       // dead lanes: the first dummy
             const double dx = xi - tx[k], dy = yi - ty[k], dz = zi - tz[k];
             const double r2 = dx * dx + dy * dy + dz * dz;
             if (MODE == 1)
@@ -207,7 +208,9 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
             //           (about 20 % of the candidates are inside the cut-off: evaluating the potential inline would
             //            execute it for nearly every wave-iteration with 80 % of the lanes masked off)
             auto process = [&]() {
-                if (lane < kTilePad) tx[T + lane] = -1e30;       // far-away dummies: the passes need no bounds checks
+                // far-away, FINITE dummies behind the last candidate: the passes need no bounds checks, and dead lanes have a
+                // harmless candidate to chew on (uninitialised LDS could hold NaN patterns: 0 * NaN would poison a force)
+                if (lane < kTilePad) { tx[T + lane] = -1e30; ty[T + lane] = 0.0; tz[T + lane] = 0.0; }
                 __builtin_amdgcn_wave_barrier();
                 if (!(P.pad0 & 1))
                 {
