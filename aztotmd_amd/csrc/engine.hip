@@ -150,6 +150,12 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
     P_.use_radii = 0;
     for (const auto& p : m.pairpots) if (p.type && p.use_radii) P_.use_radii = 1;
     P_.single_lj = (m.nSpec() == 1 && m.pairpots[0].type == AZTOT_VDW_LJ && m.elec_type == AZTOT_ELEC_NONE) ? 1 : 0;
+    {   // kernel specialisation 2: few species, every pair potential Lennard-Jones (or absent), electrostatics none or Fennell
+        bool allLj = m.nSpec() <= 4 && !P_.single_lj && (m.elec_type == AZTOT_ELEC_NONE || m.elec_type == AZTOT_ELEC_FENNEL);
+        for (const auto& p : m.pairpots) if (p.type != 0 && p.type != AZTOT_VDW_LJ) allLj = false;
+        if (m.elec_type == AZTOT_ELEC_FENNEL && m.alpha * m.rReal > 4.0) allLj = false;      // range of erfc_given_exp
+        P_.pad1 = allLj ? 2 : 0;
+    }
     std::memset(&S_, 0, sizeof(S_));
     for (int i = 0; i < m.nSpec(); i++)
     {

@@ -76,10 +76,40 @@ __device__ __forceinline__ int ld_i32(const int32_t* __restrict__ base, int j)
 // rocprof shows the kernel VALU-issue bound (VALU busy ~85 %), so this is all about instructions per wave: constant
 // LDS offsets (NS is a template parameter), no bounds clamps (far-away dummies pad the tile), Newton-refined
 // v_rcp_f64, branch-free potential.
+// erfc(x) for 0 <= x <= 4 given ex = exp(-x*x), which the caller needs anyway (Fennell / Ewald force term):
+// erfc(x) = ex * p(t), t = 3u - 2, u = 1/(1 + x/2), p = our own degree-16 fit of erfcx (tools/fit_erfcx.py; max relative error
+// 8e-15 against scipy on [0, 4]).  24 instructions instead of ocml's 140-instruction erfc plus a second exp; the host selects
+// this kernel only when alpha * rc <= 4.  tests/test_gpu_parity.py checks the result against the oracle's libm erfc.
+__device__ __forceinline__ double erfc_given_exp(double x, double ex)
+{
+    const double t = fma(3.0, fast_rcp(fma(0.5, x, 1.0)), -2.0);
+    double p = 3.11400876136111478e-10;
+    p = fma(p, t, -6.43174152465694238e-10);
+    p = fma(p, t, -2.62442874509777347e-09);
+    p = fma(p, t, 1.54097035921259372e-08);
+    p = fma(p, t, -2.06548182619811564e-08);
+    p = fma(p, t, -1.28511981631567555e-07);
+    p = fma(p, t, 7.28044471457273614e-07);
+    p = fma(p, t, -4.70993577663208179e-07);
+    p = fma(p, t, -9.92741548786899564e-06);
+    p = fma(p, t, 3.46017753152724625e-05);
+    p = fma(p, t, 1.00396629412378288e-04);
+    p = fma(p, t, -8.61280658253346654e-04);
+    p = fma(p, t, -1.60202363270953250e-03);
+    p = fma(p, t, 2.25095126335783415e-02);
+    p = fma(p, t, 1.42427001998883335e-01);
+    p = fma(p, t, 4.09818022175859609e-01);
+    p = fma(p, t, 4.27583576155806666e-01);
+    return ex * p;
+}
+
+constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-Jones / charge-product table in LDS
+
 template <int MODE, int LG>
 __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots, const DevPot& lj,
                                             const double* tx, const double* ty, const double* tz, const int32_t* ttyp, const double* trad,
-                                            int T, int slice, double xi, double yi, double zi, int ti, double radi, PairAcc& acc)
+                                            const double* pairTab, int T, int slice, double xi, double yi, double zi, int ti, double radi,
+                                            PairAcc& acc)
 {
     constexpr int NS = kWave >> LG;
     const int iters = ((T + NS - 1) / NS + 3) & ~3;        // per-lane candidates, rounded up to the unroll factor
@@ -150,22 +180,50 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 const double fm = tooBig ? 0.0 : f;
                 acc.fx = fma(fm, dx, acc.fx); acc.fy = fma(fm, dy, acc.fy); acc.fz = fma(fm, dz, acc.fz);
             }
+            else if (MODE == 2)
+            {   // every species pair is Lennard-Jones (fer_lj vdw.cpp:16-26), electrostatics none or Fennell/DSF (fennel
+                // elec.cpp:430-444); parameters per species pair come from a small LDS table: {p0, p1, p2, r2cut, kqq}
+                const double* pp = pairTab + (ti * P.nSpec + ttyp[k]) * 5;
+                const bool pairOk = live & (r2 > 0.0) & (r2 <= P.r2Max);
+                const double r2s = pairOk ? r2 : 1e300;
+                const double r2i = fast_rcp(r2s);
+                const bool vdwOk = r2s <= pp[3];
+                const double sr2 = vdwOk ? pp[1] * r2i : 0.0;
+                const double sr6 = sr2 * sr2 * sr2;
+                acc.eV = fma(0.5 * pp[0], sr6 * (sr6 - 1.0), acc.eV);
+                double f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
+                if (P.elec_type == 3)
+                {
+                    const double kqq = pairOk ? pp[4] : 0.0;
+                    const double r = sqrt(r2s), ir = r * r2i;
+                    const double ar = P.alpha * r;
+                    const double ex = exp(-ar * ar);
+                    const double erfcar = erfc_given_exp(ar, ex);
+                    acc.eC = fma(0.5 * kqq, erfcar * ir - P.el_scale + P.el_scale2 * (r - P.rReal), acc.eC);
+                    f = fma(kqq * ir, (erfcar * r2i + P.daipi2 * ex * ir) - P.el_scale2, f);
+                }
+                const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
+                nDropHalf += __popcll(__ballot(tooBig));
+                const double fm = tooBig ? 0.0 : f;
+                acc.fx = fma(fm, dx, acc.fx); acc.fy = fma(fm, dy, acc.fy); acc.fz = fma(fm, dz, acc.fz);
+            }
             else if (live && r2 > 0.0 && r2 <= P.r2Max)
                 pair_visit(P, S, pots, dx, dy, dz, r2, ti, ttyp[k], radi, trad[k], acc);
         }
     }
     // dropped pairs were counted per wave (ballot popcount); book the wave total on lane 0 in "half pair" units
-    if (MODE == 1 && threadIdx.x == 0) acc.dropped += 0.5 * (double)nDropHalf;
+    if (MODE != 0 && threadIdx.x == 0) acc.dropped += 0.5 * (double)nDropHalf;
 }
 
-template <int MODE>   // 0: generic (species table, Coulomb, radii) ; 1: one species, Lennard-Jones only
-__global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
+template <int MODE>   // 0: generic (any potential, Coulomb, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, all LJ, elec none|Fennell
+__global__ __launch_bounds__(kWave, MODE == 2 ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks)
 {
     __shared__ double tx[kTileLds], ty[kTileLds], tz[kTileLds];
-    __shared__ int32_t ttyp[MODE == 0 ? kTileLds : 1];
+    __shared__ int32_t ttyp[MODE != 1 ? kTileLds : 1];
     __shared__ double trad[MODE == 0 ? kTileLds : 1];
+    __shared__ double pairTab[MODE == 2 ? kLjSpecMax * kLjSpecMax * 5 : 1];
     __shared__ int32_t entJ[kWave], entN[kWave], entC[kWave];       // staging table: first atom, count (<= 64), image-shift code
 
     const int lane = threadIdx.x;
@@ -184,6 +242,19 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
         const double lo0 = (lx + P.cx0) * P.csz[0], lo1 = cy * P.csz[1], lo2 = cz * P.csz[2];
         const double hi0 = lo0 + P.csz[0], hi1 = lo1 + P.csz[1], hi2 = lo2 + P.csz[2];
         const DevPot lj = pots[0];
+        if (MODE == 2)
+        {
+            const int np = P.nSpec * P.nSpec;
+            if (lane < np)
+            {
+                const DevPot v = pots[lane];
+                const int a = lane / P.nSpec, b = lane - a * P.nSpec;
+                pairTab[lane * 5 + 0] = v.p0; pairTab[lane * 5 + 1] = v.p1; pairTab[lane * 5 + 2] = v.p2;
+                pairTab[lane * 5 + 3] = v.type ? v.r2cut : -1.0;
+                pairTab[lane * 5 + 4] = (S.charged[a] && S.charged[b]) ? S.charge[a] * S.charge[b] * P.fcoul : 0.0;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         for (int i0 = ib; i0 < ie; i0 += kWave)
         {
             const int nthis = min(kWave, ie - i0);
@@ -197,7 +268,8 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
             if (validI)
             {
                 xi = A.x[myi]; yi = A.y[myi]; zi = A.z[myi];
-                if (MODE == 0) { ti = A.type[myi]; if (P.use_radii) radi = A.rad[myi]; }
+                if (MODE != 1) ti = A.type[myi];
+                if (MODE == 0 && P.use_radii) radi = A.rad[myi];
             }
             acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0; acc.eV = 0.0; acc.eC = 0.0; acc.dropped = 0.0;
             int T = 0;
@@ -214,9 +286,9 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
                 __builtin_amdgcn_wave_barrier();
                 if (!(P.pad0 & 1))
                 {
-                    if (lg == 4) tile_passes<MODE, 4>(P, S, pots, lj, tx, ty, tz, ttyp, trad, T, slice, xi, yi, zi, ti, radi, acc);
-                    else if (lg == 5) tile_passes<MODE, 5>(P, S, pots, lj, tx, ty, tz, ttyp, trad, T, slice, xi, yi, zi, ti, radi, acc);
-                    else tile_passes<MODE, 6>(P, S, pots, lj, tx, ty, tz, ttyp, trad, T, slice, xi, yi, zi, ti, radi, acc);
+                    if (lg == 4) tile_passes<MODE, 4>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
+                    else if (lg == 5) tile_passes<MODE, 5>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
+                    else tile_passes<MODE, 6>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
                 }
                 __builtin_amdgcn_wave_barrier();
                 T = 0;
@@ -293,7 +365,8 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
                             if (lane < gjn[u])
                             {
                                 gx[u] = ld_f64(A.x, j); gy[u] = ld_f64(A.y, j); gz[u] = ld_f64(A.z, j);
-                                if (MODE == 0) { gtyp[u] = ld_i32(A.type, j); if (P.use_radii) grad[u] = ld_f64(A.rad, j); }
+                                if (MODE != 1) gtyp[u] = ld_i32(A.type, j);
+                                if (MODE == 0 && P.use_radii) grad[u] = ld_f64(A.rad, j);
                             }
                         }
 #pragma unroll
@@ -319,7 +392,8 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
                                 {
                                     const int pp = T + lanes_below(mask);
                                     tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
-                                    if (MODE == 0) { ttyp[pp] = gtyp[u]; trad[pp] = grad[u]; }
+                                    if (MODE != 1) ttyp[pp] = gtyp[u];
+                                    if (MODE == 0) trad[pp] = grad[u];
                                 }
                                 T += __popcll(mask);
                             }
@@ -341,7 +415,7 @@ __global__ __launch_bounds__(kWave) void k_pair_tile(StepParams P, SpecTable S, 
             if (validI && slice == 0)
             {
                 double q = 0.0;
-                if (MODE == 0) q = S.charge[ti];
+                if (MODE != 1) q = S.charge[ti];
                 A.fx[myi] = -q * P.E[0] + acc.fx;          // clear_force integrators.cpp:17-39
                 A.fy[myi] = -q * P.E[1] + acc.fy;
                 A.fz[myi] = -q * P.E[2] + acc.fz;
@@ -367,6 +441,8 @@ inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevP
     const int grid = pair_tile_grid(P);
     if (P.single_lj)
         hipLaunchKernelGGL(k_pair_tile<1>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
+    else if (P.pad1 == 2)
+        hipLaunchKernelGGL(k_pair_tile<2>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
     else
         hipLaunchKernelGGL(k_pair_tile<0>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
 }
