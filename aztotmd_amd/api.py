@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 STAT_FIELDS = ("step", "time", "engTot", "engKin", "engVdW", "engCoul", "engElecField", "engTemp", "engPot", "temperature",
-               "posMom", "negMom", "posCross", "negCross", "pressure", "pairs_dropped", "n_cells", "nose_chit", "nose_conint")
+               "posMom", "negMom", "posCross", "negCross", "pressure", "pairs_dropped", "n_cells", "nose_chit", "nose_conint",
+               "engBond", "engAngle")
 
 
 class AztotError(RuntimeError):
@@ -45,6 +46,21 @@ class _System(C.Structure):
                 ("species", C.POINTER(_Species)), ("vdw", C.POINTER(_Vdw)), ("control", _Control)]
 
 
+class _BondType(C.Structure):
+    _fields_ = [("spec_a", C.c_int32), ("spec_b", C.c_int32), ("type", C.c_int32), ("p", C.c_double * 5)]
+
+
+class _AngleType(C.Structure):
+    _fields_ = [("central", C.c_int32), ("type", C.c_int32), ("k", C.c_double), ("cos0", C.c_double)]
+
+
+class _Bonded(C.Structure):
+    _fields_ = [("n_bond_types", C.c_int32), ("n_angle_types", C.c_int32), ("n_bonds", C.c_int32), ("n_angles", C.c_int32),
+                ("bond_types", C.POINTER(_BondType)), ("angle_types", C.POINTER(_AngleType)),
+                ("bond_a", _ip), ("bond_b", _ip), ("bond_type", _ip),
+                ("angle_c", _ip), ("angle_l1", _ip), ("angle_l2", _ip), ("angle_type", _ip)]
+
+
 class _Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("initial_forces", C.c_int32), ("center_box", C.c_int32), ("seed", C.c_uint64),
                 ("pair_variant", C.c_int32), ("cell_size", C.c_double), ("use_graph", C.c_int32), ("profile", C.c_int32),
@@ -56,7 +72,7 @@ class _Stats(C.Structure):
                 ("engCoul", C.c_double), ("engElecField", C.c_double), ("engTemp", C.c_double), ("engPot", C.c_double),
                 ("temperature", C.c_double), ("posMom", C.c_double * 3), ("negMom", C.c_double * 3), ("posCross", C.c_int64 * 3),
                 ("negCross", C.c_int64 * 3), ("pressure", C.c_double), ("pairs_dropped", C.c_int64), ("n_cells", C.c_int64),
-                ("nose_chit", C.c_double), ("nose_conint", C.c_double)]
+                ("nose_chit", C.c_double), ("nose_conint", C.c_double), ("engBond", C.c_double), ("engAngle", C.c_double)]
 
 
 class _State(C.Structure):
@@ -66,7 +82,7 @@ class _State(C.Structure):
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
 
-EXPORTS = ("aztot_init_md", "aztot_model_create", "aztot_model_query", "aztot_model_species_name", "aztot_free_md", "aztot_default_options",
+EXPORTS = ("aztot_init_md", "aztot_model_create", "aztot_model_set_bonded", "aztot_model_query", "aztot_model_species_name", "aztot_free_md", "aztot_default_options",
            "aztot_init_device", "aztot_free_device", "aztot_step", "aztot_forces", "aztot_get_stats", "aztot_md_to_host",
            "aztot_set_state", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id",
            "aztot_init_device_slab", "aztot_last_error", "aztot_version")
@@ -103,6 +119,7 @@ def lib():
         L.aztot_init_md.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.aztot_model_create.argtypes = [C.POINTER(_System), C.POINTER(C.c_void_p)]
         L.aztot_model_query.argtypes = [C.c_void_p, C.c_char_p, _dp, C.c_int]
+        L.aztot_model_set_bonded.argtypes = [C.c_void_p, C.POINTER(_Bonded)]
         L.aztot_free_md.argtypes = [C.c_void_p]
         L.aztot_free_md.restype = None
         L.aztot_default_options.argtypes = [C.POINTER(_Options)]
@@ -187,7 +204,32 @@ class Model:
         c.stat = int(case.get("stat", 200))
         h = C.c_void_p()
         _check(lib().aztot_model_create(C.byref(s), C.byref(h)))
-        return cls(h)
+        m = cls(h)
+        if case.get("bond_types") or case.get("angle_types"):
+            m.set_bonded(case.get("bond_types") or [], case.get("angle_types") or [], case.get("bonds"), case.get("angles"))
+        return m
+
+    def set_bonded(self, bond_types, angle_types, bonds=None, angles=None):
+        """bond_types: [(specA, specB, type_id, [p..])], angle_types: [(central, type_id, [k, cos0])],
+        bonds: (n,3) int array (at1, at2, type id 1-based) = bonds.txt, angles: (n,4) (central, lig1, lig2, type id) = angles.txt."""
+        bt = (_BondType * max(len(bond_types), 1))()
+        for i, (a, b, t, p) in enumerate(bond_types):
+            bt[i].spec_a, bt[i].spec_b, bt[i].type = a, b, t
+            for k, v in enumerate(list(p)[:5]):
+                bt[i].p[k] = v
+        at = (_AngleType * max(len(angle_types), 1))()
+        for i, (c, t, p) in enumerate(angle_types):
+            at[i].central, at[i].type, at[i].k, at[i].cos0 = c, t, p[0], p[1]
+        b = np.ascontiguousarray(bonds if bonds is not None else np.zeros((0, 3)), dtype=np.int32).reshape(-1, 3)
+        a = np.ascontiguousarray(angles if angles is not None else np.zeros((0, 4)), dtype=np.int32).reshape(-1, 4)
+        bc = [np.ascontiguousarray(b[:, k]) for k in range(3)]
+        ac = [np.ascontiguousarray(a[:, k]) for k in range(4)]
+        d = _Bonded()
+        d.n_bond_types, d.n_angle_types, d.n_bonds, d.n_angles = len(bond_types), len(angle_types), len(b), len(a)
+        d.bond_types, d.angle_types = bt, at
+        d.bond_a, d.bond_b, d.bond_type = [c.ctypes.data_as(_ip) for c in bc]
+        d.angle_c, d.angle_l1, d.angle_l2, d.angle_type = [c.ctypes.data_as(_ip) for c in ac]
+        _check(lib().aztot_model_set_bonded(self.h, C.byref(d)))
 
     def query(self, key, seed=None):
         n = _check(lib().aztot_model_query(self.h, key.encode(), None, 0))

@@ -68,6 +68,24 @@ int aztot_model_create(const aztot_system* sys, aztot_model** out)
     });
 }
 
+int aztot_model_set_bonded(aztot_model* h, const aztot_bonded* b)
+{
+    if (!h || !b) return fail(AZTOT_ERR_ARG, "null argument");
+    if (b->n_bond_types < 0 || b->n_angle_types < 0 || b->n_bonds < 0 || b->n_angles < 0) return fail(AZTOT_ERR_ARG, "negative count in aztot_bonded");
+    if ((b->n_bond_types && !b->bond_types) || (b->n_angle_types && !b->angle_types) || (b->n_bonds && !(b->bond_a && b->bond_b && b->bond_type)) ||
+        (b->n_angles && !(b->angle_c && b->angle_l1 && b->angle_l2 && b->angle_type)))
+        return fail(AZTOT_ERR_ARG, "null array in aztot_bonded");
+    return guarded([&] {
+        Model m = h->m;                 // all-or-nothing: the model is replaced only if every line is accepted
+        m.bondTypes.clear(); m.angleTypes.clear();
+        for (int i = 0; i < b->n_bond_types; i++) add_bond_type(m, b->bond_types[i].spec_a, b->bond_types[i].spec_b, b->bond_types[i].type, b->bond_types[i].p);
+        for (int i = 0; i < b->n_angle_types; i++) add_angle_type(m, b->angle_types[i].central, b->angle_types[i].type, b->angle_types[i].k, b->angle_types[i].cos0);
+        set_bond_list(m, b->n_bonds, b->bond_a, b->bond_b, b->bond_type);
+        set_angle_list(m, b->n_angles, b->angle_c, b->angle_l1, b->angle_l2, b->angle_type);
+        h->m = std::move(m);
+    });
+}
+
 void aztot_free_md(aztot_model* m) { delete m; }
 
 int aztot_model_species_name(const aztot_model* m, int i, char* buf, int cap)
@@ -82,6 +100,8 @@ int aztot_model_species_name(const aztot_model* m, int i, char* buf, int cap)
 //  rmax r2max degfree tkin cell_list use_cell_list stat init_vel elecfield nthread kB m_scale fcoul
 //  species (per species: mass_amu, mass, charge, charged, frozen, rMass_hdt, radA, radB, mxEng, number)
 //  vdw (per ordered species pair a*nSpec+b: type, r2cut, p0..p4, use_radii)
+//  n_bonded (bond types, angle types, bonds, angles)  bond_types (type, spec1, spec2, p0..p4)  angle_types (type, central, k, cos0)
+//  bonds (at1, at2, type id per bond, after the turn of read_bondlist)  angles (central, lig1, lig2, type id)
 //  types x y z vx vy vz   (per atom)    photons uvx uvy uvz (radiative thermostat tables; seed = first element of `out` on entry for photons)
 int aztot_model_query(const aztot_model* h, const char* key, double* out, int cap)
 {
@@ -129,6 +149,16 @@ int aztot_model_query(const aztot_model* h, const char* key, double* out, int ca
         else if (k == "vdw")
             for (const auto& p : m.pairpots)
             { double r[] = {(double)p.type, p.r2cut, p.p0, p.p1, p.p2, p.p3, p.p4, (double)p.use_radii}; v.insert(v.end(), r, r + 8); }
+        else if (k == "n_bonded") v = {(double)m.bondTypes.size(), (double)m.angleTypes.size(), (double)m.bondA.size(), (double)m.angC.size()};
+        else if (k == "bond_types")
+            for (const auto& b : m.bondTypes)
+            { double r[] = {(double)b.type, (double)b.spec1, (double)b.spec2, b.p[0], b.p[1], b.p[2], b.p[3], b.p[4]}; v.insert(v.end(), r, r + 8); }
+        else if (k == "angle_types")
+            for (const auto& a : m.angleTypes) { double r[] = {(double)a.type, (double)a.central, a.k, a.cos0}; v.insert(v.end(), r, r + 4); }
+        else if (k == "bonds")
+            for (size_t i = 0; i < m.bondA.size(); i++) { v.push_back(m.bondA[i]); v.push_back(m.bondB[i]); v.push_back(m.bondT[i]); }
+        else if (k == "angles")
+            for (size_t i = 0; i < m.angC.size(); i++) { v.push_back(m.angC[i]); v.push_back(m.angL1[i]); v.push_back(m.angL2[i]); v.push_back(m.angT[i]); }
         else if (k == "types") { v.resize(m.nAt); for (int i = 0; i < m.nAt; i++) v[i] = m.types[i]; }
         else if (k == "x") per_atom(m.x);
         else if (k == "y") per_atom(m.y);

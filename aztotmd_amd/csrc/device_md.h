@@ -34,6 +34,24 @@ struct DevPot                     // cudaVdW, cuStruct.h:50-63, without the devi
     double p0, p1, p2, p3, p4, r2cut;
 };
 
+// bonded terms ("next" row f2).  The reference keeps bond / angle lists of atom *indices* and rewrites them after every
+// sort (cuSort.cu:199-236); here the lists are static per-atom CSR tables keyed by the persistent atom id, and the sort
+// publishes one id -> current-index map (idxOfId) instead.
+struct DevBondType { int32_t type, pad; double p0, p1, p2, p3, p4; };     // cudaBond, cuStruct.h:66-78 (constant bonds)
+struct DevAngleType { double k, cos0; };                                 // cudaAngle: harmonic cosine only
+struct BondEntry { int32_t partner; int32_t typeFirst; };                // partner id ; type id | (this atom is at1) << 30
+struct AngleEntry { int32_t roleType, c, l1, l2; };                      // role (0 central, 1 lig1, 2 lig2) | type id << 2 ; atom ids
+struct BondedTables
+{
+    const int32_t* bondStart;        // [nAtGlobal + 1]
+    const BondEntry* bondEnt;
+    const int32_t* angStart;         // [nAtGlobal + 1]
+    const AngleEntry* angEnt;
+    const DevBondType* btypes;       // [nBondTypes + 1], [0] unused (the reference's reserved 'none')
+    const DevAngleType* atypes;
+    int32_t* idxOfId;                // [nAtGlobal]: index in the sorted arrays, verified against A.id on use
+};
+
 // uniform parameters of the step (kernel argument, by value)
 struct StepParams
 {
@@ -72,7 +90,7 @@ enum PartialSlot
 {
     PS_EFIELD = 0, PS_MOM_XN, PS_MOM_XP, PS_MOM_YN, PS_MOM_YP, PS_MOM_ZN, PS_MOM_ZP,
     PS_CNT_XN, PS_CNT_XP, PS_CNT_YN, PS_CNT_YP, PS_CNT_ZN, PS_CNT_ZP,
-    PS_EVDW, PS_ECOUL, PS_DROPPED, PS_EKIN, PS_ETEMP, PS_COUNT
+    PS_EVDW, PS_ECOUL, PS_DROPPED, PS_EKIN, PS_ETEMP, PS_EBOND, PS_EANGLE, PS_COUNT
 };
 
 // device-resident scalars (the energy / momentum block of cudaMD, cuStruct.h:230-247)
@@ -80,6 +98,7 @@ struct DevStats
 {
     long long step;
     double engKin, engVdW, engCoul, engElecField, engTemp, engTot, engPot, temperature;
+    double engBond, engAngle;     // exec_bondlist bonds.cpp:1218 / exec_anglelist angles.cpp:240
     double mom[6];                // Xn, Xp, Yn, Yp, Zn, Zp accumulated over the run (box.cpp:230-295)
     long long cross[6];
     long long dropped;

@@ -37,7 +37,7 @@ public:
     Engine(const Engine&) = delete;
 
     void step(int nsteps);
-    void forces();                          // sort + pair forces on the current positions
+    void forces(bool withBonded = true);    // sort + pair forces (+ bonds / angles) on the current positions
     void get_stats(aztot_stats& out);
     void md_to_host(aztot_state& out);
     void set_state(const aztot_state& in);
@@ -50,7 +50,8 @@ private:
     void choose_cells();
     void allocate();
     void upload_initial();
-    void sort_and_forces(bool integrate_first);
+    void upload_bonded();
+    void sort_and_forces(bool integrate_first, bool withBonded = true);
     void launch_step_kernels();
     void launch_pair();
     void exchange_halo();
@@ -90,6 +91,8 @@ private:
     char* dMsg_[4] = {nullptr, nullptr, nullptr, nullptr};   // sendLeft, sendRight, fromLeft, fromRight
     MsgLayout lay_{};
     int pairBlocks_ = 0, pairBlocksUsed_ = 0;
+    BondedTables bonded_{};         // all-null when the model has no bonds / angles
+    bool hasBonded_ = false;
 
     // statistics window for the wall-momentum pressure (main.cpp:143-163)
     double lastMom_[6] = {0, 0, 0, 0, 0, 0};

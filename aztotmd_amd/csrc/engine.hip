@@ -7,6 +7,7 @@
 #include <stdexcept>
 
 #include "exchange.h"
+#include "bonded.hip.h"
 #include "kernels.hip.h"
 #include "pair_tile.hip.h"
 #include "slab.hip.h"
@@ -166,6 +167,7 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
     }
     choose_cells();
     allocate();
+    upload_bonded();
     if (nranks_ > 1 && !xch_)
     {   // options.reserved[1]: loopback measurement mode (see LoopbackExchanger)
         ownedXch_.reset(new LoopbackExchanger((P_.ncxLocal - 2 * P_.hw[0]) * P_.csz[0], P_.L[0], lay_.mig_offset(), lay_.halo_offset(),
@@ -254,6 +256,61 @@ void Engine::allocate()
     HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
+// Static per-atom tables of the bonded terms, keyed by atom id and replicated on every rank (like the reference's
+// host-side lists, cuBonds.cu / cuAngles.cu); entries of one atom keep list order, so the summation order is fixed.
+void Engine::upload_bonded()
+{
+    const Model& m = model_;
+    const size_t nb = m.bondA.size(), na = m.angC.size();
+    hasBonded_ = (nb + na) > 0;
+    if (!hasBonded_) return;
+    const int N = m.nAt;
+    auto up = [&](const void* src, size_t bytes) {
+        void* p = nullptr; HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16))); allocs_.push_back(p);
+        if (bytes) HIP_CHECK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return p;
+    };
+    std::vector<int32_t> bs(N + 1, 0), as(N + 1, 0);
+    for (size_t k = 0; k < nb; k++) { bs[m.bondA[k] + 1]++; bs[m.bondB[k] + 1]++; }
+    for (size_t k = 0; k < na; k++) { as[m.angC[k] + 1]++; as[m.angL1[k] + 1]++; as[m.angL2[k] + 1]++; }
+    for (int i = 0; i < N; i++) { bs[i + 1] += bs[i]; as[i + 1] += as[i]; }
+    std::vector<BondEntry> be(2 * nb);
+    std::vector<AngleEntry> ae(3 * na);
+    {
+        std::vector<int32_t> fill(bs.begin(), bs.end() - 1);
+        for (size_t k = 0; k < nb; k++)
+        {
+            be[fill[m.bondA[k]]++] = BondEntry{m.bondB[k], m.bondT[k] | (1 << 30)};
+            be[fill[m.bondB[k]]++] = BondEntry{m.bondA[k], m.bondT[k]};
+        }
+        fill.assign(as.begin(), as.end() - 1);
+        for (size_t k = 0; k < na; k++)
+        {
+            const int32_t c = m.angC[k], l1 = m.angL1[k], l2 = m.angL2[k], t = m.angT[k] << 2;
+            ae[fill[c]++] = AngleEntry{t | 0, c, l1, l2};
+            ae[fill[l1]++] = AngleEntry{t | 1, c, l1, l2};
+            ae[fill[l2]++] = AngleEntry{t | 2, c, l1, l2};
+        }
+    }
+    std::vector<DevBondType> bt(m.bondTypes.size() + 1);
+    std::memset(bt.data(), 0, sizeof(DevBondType) * bt.size());
+    for (size_t k = 0; k < m.bondTypes.size(); k++)
+    {
+        const BondType& b = m.bondTypes[k];
+        bt[k + 1] = DevBondType{b.type, 0, b.p[0], b.p[1], b.p[2], b.p[3], b.p[4]};
+    }
+    std::vector<DevAngleType> at(m.angleTypes.size() + 1, DevAngleType{0.0, 0.0});
+    for (size_t k = 0; k < m.angleTypes.size(); k++) at[k + 1] = DevAngleType{m.angleTypes[k].k, m.angleTypes[k].cos0};
+    bonded_.bondStart = (const int32_t*)up(bs.data(), sizeof(int32_t) * bs.size());
+    bonded_.bondEnt = (const BondEntry*)up(be.data(), sizeof(BondEntry) * be.size());
+    bonded_.angStart = (const int32_t*)up(as.data(), sizeof(int32_t) * as.size());
+    bonded_.angEnt = (const AngleEntry*)up(ae.data(), sizeof(AngleEntry) * ae.size());
+    bonded_.btypes = (const DevBondType*)up(bt.data(), sizeof(DevBondType) * bt.size());
+    bonded_.atypes = (const DevAngleType*)up(at.data(), sizeof(DevAngleType) * at.size());
+    std::vector<int32_t> none(N, -1);
+    bonded_.idxOfId = (int32_t*)up(none.data(), sizeof(int32_t) * (size_t)N);
+}
+
 void Engine::upload_initial()
 {
     const Model& m = model_;
@@ -300,7 +357,8 @@ void Engine::upload_initial()
     Counts c{};
     c.ownedBegin = 0; c.ownedEnd = n; c.nTotal = n; c.srcBegin = 0; c.srcEnd = n;
     HIP_CHECK(hipMemcpy(dCounts_, &c, sizeof(Counts), hipMemcpyHostToDevice));
-    if (opt_.initial_forces) forces();
+    // init_serial computes all_pairs only (sys_init.cpp:1181-1184): bonds and angles first act in step 1's force phase
+    if (opt_.initial_forces) forces(false);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -336,7 +394,7 @@ void Engine::exchange_halo()
 // ---------------------------------------------------------------------------------------------------
 // iter_fastCellList (cuPairs.cu:2519-2567): histogram -> [halo] -> scan -> sort -> pair forces
 // ---------------------------------------------------------------------------------------------------
-void Engine::sort_and_forces(bool integrate_first)
+void Engine::sort_and_forces(bool integrate_first, bool withBonded)
 {
     const int gridAtoms = div_up(capacity_, kBlock);
     if (integrate_first)
@@ -364,10 +422,14 @@ void Engine::sort_and_forces(bool integrate_first)
     });
     timed("rank_gather", [&] {
         hipLaunchKernelGGL(k_rank_gather, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellStart_, dTmpId_, dTmpSrc_, dTmpCell_, cur(), oth(),
-                           dCellOfSorted_, 0, P_, dCounts_);
+                           dCellOfSorted_, 0, P_, dCounts_, bonded_.idxOfId);
     });
     cur_ ^= 1;
     launch_pair();
+    if (hasBonded_ && withBonded)      // exec_bondlist + exec_anglelist, main.cpp:101-104 (GPU path: main.cu:307-312,353-363)
+        timed("bonded", [&] {
+            hipLaunchKernelGGL(k_bonded, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, cur(), dCounts_, bonded_, dPartials_, maxBlocks_);
+        });
 }
 
 void Engine::collect_and_finalize(unsigned slotMask)
@@ -379,11 +441,12 @@ void Engine::collect_and_finalize(unsigned slotMask)
     timed("finalize", [&] { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, stream_, P_, dStats_, dStage_, slotMask); });
 }
 
-void Engine::forces()
+void Engine::forces(bool withBonded)
 {
-    sort_and_forces(false);
+    sort_and_forces(false, withBonded);
     // energies of this configuration; kinetic energy and wall counters are left untouched
-    const unsigned mask = (1u << PS_EVDW) | (1u << PS_ECOUL) | (1u << PS_DROPPED);
+    unsigned mask = (1u << PS_EVDW) | (1u << PS_ECOUL) | (1u << PS_DROPPED);
+    if (hasBonded_ && withBonded) mask |= (1u << PS_EBOND) | (1u << PS_EANGLE);
     collect_and_finalize(mask);
     HIP_CHECK(hipMemsetAsync(dCellCount_, 0, sizeof(int32_t) * (size_t)(nCellAlloc_ + 1), stream_));
     sync();
@@ -432,6 +495,7 @@ void Engine::finish_steps()
     unsigned mask = (1u << PS_COUNT) - 1u;
     if (P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE) mask &= ~(1u << PS_EKIN);   // k_reduce_kin / k_scale_decision own engKin then
     if (!(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_RADI)) mask &= ~(1u << PS_ETEMP);
+    if (!hasBonded_) mask &= ~((1u << PS_EBOND) | (1u << PS_EANGLE));
     collect_and_finalize(mask);
 }
 
@@ -466,10 +530,13 @@ void Engine::step(int nsteps)
 
 void Engine::check_overflow()
 {
-    if (nranks_ <= 1) return;
+    if (nranks_ <= 1 && !hasBonded_) return;
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
     if (c.overflow) throw std::runtime_error("slab decomposition: a fixed-capacity halo/migration/atom buffer overflowed");
+    if (c.bondedMissing)
+        throw std::runtime_error("slab decomposition: a bond / angle partner was not resident on the rank that owns the atom "
+                                 "(bonded terms must span less than the halo width)");
 }
 
 void Engine::get_stats(aztot_stats& out)
@@ -480,14 +547,15 @@ void Engine::get_stats(aztot_stats& out)
     double v[24];
     v[0] = s.engKin; v[1] = s.engVdW; v[2] = s.engCoul; v[3] = s.engElecField; v[4] = s.engTemp;
     for (int k = 0; k < 6; k++) { v[5 + k] = s.mom[k]; v[11 + k] = (double)s.cross[k]; }
-    v[17] = (double)s.dropped;
-    if (nranks_ > 1) xch_->allreduce_sum(v, 18, stream_);
+    v[17] = (double)s.dropped; v[18] = s.engBond; v[19] = s.engAngle;
+    if (nranks_ > 1) xch_->allreduce_sum(v, 20, stream_);
     std::memset(&out, 0, sizeof(out));
     out.step = s.step;
     out.time = s.step * model_.tSt;
     out.engKin = v[0]; out.engVdW = v[1]; out.engCoul = v[2]; out.engElecField = v[3]; out.engTemp = v[4];
     out.engPot = out.engCoul + out.engVdW;
-    out.engTot = out.engElecField + out.engVdW + out.engCoul + out.engKin;          // calc_chars integrators.cpp:72
+    out.engBond = v[18]; out.engAngle = v[19];
+    out.engTot = out.engElecField + out.engVdW + out.engCoul + out.engKin + out.engBond + out.engAngle;   // calc_chars integrators.cpp:71
     out.temperature = 2.0 * out.engKin * model_.revDegFree * (1.0 / units::kB);     // integrators.cpp:67
     out.negMom[0] = v[5]; out.posMom[0] = v[6]; out.negMom[1] = v[7]; out.posMom[1] = v[8]; out.negMom[2] = v[9]; out.posMom[2] = v[10];
     out.negCross[0] = (int64_t)v[11]; out.posCross[0] = (int64_t)v[12]; out.negCross[1] = (int64_t)v[13];

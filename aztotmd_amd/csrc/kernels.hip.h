@@ -223,7 +223,7 @@ struct Counts
     int32_t srcBegin, srcEnd;       // pre-sort source range: old owned range + atoms appended by k_unpack
     int32_t nRecv;                  // atoms appended by k_unpack in the step in flight
     int32_t overflow;               // sticky: a fixed-capacity buffer was too small
-    int32_t pad;
+    int32_t bondedMissing;          // sticky: a bond / angle partner was not resident on this rank (k_bonded)
 };
 
 __device__ __forceinline__ int wave_append(bool flag, int32_t* counter)
@@ -430,7 +430,8 @@ __global__ __launch_bounds__(kBlock) void k_place(const Counts* __restrict__ cnt
 __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict__ cnt, const int32_t* __restrict__ cellStart,
                                                         const int32_t* __restrict__ tmpId, const int32_t* __restrict__ tmpSrc,
                                                         const int32_t* __restrict__ tmpCell, AtomArrays src, AtomArrays dst,
-                                                        int32_t* __restrict__ cellOfSorted, int carryForces, StepParams P, Counts* cntOut)
+                                                        int32_t* __restrict__ cellOfSorted, int carryForces, StepParams P, Counts* cntOut,
+                                                        int32_t* __restrict__ idxOfId)
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p == 0)
@@ -457,6 +458,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
     dst.type[d] = src.type[i]; dst.id[d] = myId;
     if (carryForces) { dst.fx[d] = src.fx[i]; dst.fy[d] = src.fy[i]; dst.fz[d] = src.fz[i]; }
     cellOfSorted[d] = c;
+    if (idxOfId) idxOfId[myId] = d;     // bonded terms find their partners through this map (replaces cuSort.cu:199-236)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -761,8 +763,10 @@ __global__ void k_finalize(StepParams P, DevStats* st, const double* __restrict_
     }
     st->dropped += (long long)(sums[PS_DROPPED] + 0.5);
     st->temperature = 2.0 * st->engKin * P.revDegFree * P.rkB;
+    st->engBond = sums[PS_EBOND];
+    st->engAngle = sums[PS_EANGLE];
     st->engPot = st->engCoul + st->engVdW;
-    st->engTot = st->engElecField + st->engVdW + st->engCoul + st->engKin;
+    st->engTot = st->engElecField + st->engVdW + st->engCoul + st->engKin + st->engBond + st->engAngle;
 }
 
 }  // namespace aztot

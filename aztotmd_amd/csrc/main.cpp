@@ -65,9 +65,15 @@ int main(int argc, char** argv)
 
     FILE* sf = std::fopen((out + "/stat.dat").c_str(), "w");
     if (!sf) { std::perror("stat.dat"); return 1; }
-    std::fprintf(sf, "time\tstep\tengTot\tengKin\tengVdW\tengCoul1\tengCoul2%s\tmomPx\tmomNx\tmomPy\tmomNy\tmomPz\tmomNz\tpress\n", radi ? "\tengTerm" : "");
-    std::fprintf(sf, "time, ps\tstep, n\tengTot, eV\tengKin, eV\tengVdW, eV\tengCoul1, eV\tengCoul2, eV%s"
-                     "\tmomPx, eVps/A\tmomNx, eVps/A\tmomPy, eVps/A\tmomNy, eVps/A\tmomPz, eVps/A\tmomNz, eVps/A\tpress, atm\n", radi ? "\tengTerm, eV" : "");
+    // columns follow start_stat (cuStat.cu:300-330): engBnd / engAngle appear when field.txt declares bond / angle types
+    double nbd[4] = {0, 0, 0, 0};
+    aztot_model_query(model, "n_bonded", nbd, 4);
+    const bool hasB = nbd[0] > 0, hasA = nbd[1] > 0;
+    std::fprintf(sf, "time\tstep\tengTot\tengKin\tengVdW\tengCoul1\tengCoul2%s%s%s\tmomPx\tmomNx\tmomPy\tmomNy\tmomPz\tmomNz\tpress\n", radi ? "\tengTerm" : "",
+                 hasB ? "\tengBnd" : "", hasA ? "\tengAngle" : "");
+    std::fprintf(sf, "time, ps\tstep, n\tengTot, eV\tengKin, eV\tengVdW, eV\tengCoul1, eV\tengCoul2, eV%s%s%s"
+                     "\tmomPx, eVps/A\tmomNx, eVps/A\tmomPy, eVps/A\tmomNy, eVps/A\tmomPz, eVps/A\tmomNz, eVps/A\tpress, atm\n", radi ? "\tengTerm, eV" : "",
+                 hasB ? "\tengBnd, eV" : "", hasA ? "\tengAngle, eV" : "");
     aztot_stats st;
     for (int done = 0; done < nStep;)
     {
@@ -77,6 +83,8 @@ int main(int argc, char** argv)
         if (aztot_get_stats(md, &st) != AZTOT_OK) die("stats");
         std::fprintf(sf, "%f\t%d\t%f\t%f\t%f\t%f\t%f", st.time, (int)st.step, st.engTot, st.engKin, st.engVdW, st.engCoul, 0.0);
         if (radi) std::fprintf(sf, "\t%f", st.engTemp);
+        if (hasB) std::fprintf(sf, "\t%f", st.engBond);
+        if (hasA) std::fprintf(sf, "\t%f", st.engAngle);
         std::fprintf(sf, "\t%f\t%f\t%f\t%f\t%f\t%f\t%f\n", st.posMom[0], st.negMom[0], st.posMom[1], st.negMom[1], st.posMom[2], st.negMom[2], st.pressure);
         std::printf("time=%f(%d) Tot=%f Kin=%f VdW=%f Coul=%f T=%f P=%f\n", st.time, (int)st.step, st.engTot, st.engKin, st.engVdW, st.engCoul, st.temperature, st.pressure);
     }

@@ -49,6 +49,20 @@ struct PairPot                                             // VdW, dataStruct.h:
     double rcut = 0;
 };
 
+struct BondType                                            // Bond, dataStruct.h:321-339 ('con con' bonds only)
+{
+    int type = 0;           // 1 harm, 2 mors, 3 pdn, 4 buck, 5 e612 (bonds.cpp:158-252)
+    int spec1 = 0, spec2 = 0;
+    double p[5] = {0, 0, 0, 0, 0};
+};
+
+struct AngleType                                           // Angle, dataStruct.h:341-346
+{
+    int type = 0;           // 1 hcos
+    int central = 0;
+    double k = 0, cos0 = 0;
+};
+
 struct Model
 {
     // Atoms (dataStruct.h:305-318)
@@ -64,6 +78,12 @@ struct Model
     double minRvdw = 999999.9, maxRvdw = 0.0;
     int charged_spec = 0;
     int has_radii = 0;
+    // bonded terms (Field, dataStruct.h:389-410).  Type ids are the reference's: 1-based, [0] is its reserved 'none'
+    // (sys_init.cpp:293-295,414-420), so bondTypes[k] below is id k + 1.
+    std::vector<BondType> bondTypes;
+    std::vector<AngleType> angleTypes;
+    std::vector<int32_t> bondA, bondB, bondT;         // at1 (carries the type's spec1 after read_bondlist's turn), at2, type id
+    std::vector<int32_t> angC, angL1, angL2, angT;    // central, ligands, type id
     // Sim / control.txt
     double tSt = 0;
     int nSt = 0, nEq = 0, freqEq = 0;
@@ -102,6 +122,12 @@ void init_md(const std::string& dir, Model& m);
 void model_from_system(const aztot_system& sys, Model& m);
 // prepare_elec + derived parameters + initial velocities (init_md tail, sys_init.cpp:1047-1119)
 void finish_model(Model& m, uint64_t seed);
+// bonded lists (read_bondlist bonds.cpp:25-110, read_anglelist angles.cpp:22-60): validates against the type tables
+// and the atoms' species, turns bonds so that the first atom carries spec1.  Replaces any previous lists.
+void set_bond_list(Model& m, int n, const int32_t* a, const int32_t* b, const int32_t* t);
+void set_angle_list(Model& m, int n, const int32_t* c, const int32_t* l1, const int32_t* l2, const int32_t* t);
+void add_bond_type(Model& m, int spec1, int spec2, int type, const double p[5]);
+void add_angle_type(Model& m, int central, int type, double k, double cos0);
 // raw user vdw line -> prepared potential (read_vdw, vdw.cpp:261-299)
 PairPot prepare_vdw(int type, double rcut, const double p[5]);
 void center_box(Model& m);   // box.cpp:337-384

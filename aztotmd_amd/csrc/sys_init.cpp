@@ -57,6 +57,14 @@ int vdw_type_by_name(const char* s)
 }
 const int kVdwNParam[8] = {0, 2, 3, 3, 5, 3, 3, 4};   // vdw.cpp:195
 
+int bond_type_by_name(const char* s)
+{   // bonds.cpp:158-252
+    static const char* names[] = {"harm", "mors", "pdn", "buck", "e612"};
+    for (int i = 0; i < 5; i++) if (std::strcmp(s, names[i]) == 0) return i + 1;
+    return 0;
+}
+const int kBondNParam[6] = {0, 2, 4, 5, 3, 5};
+
 int species_by_name(const Model& m, const char* name)
 {
     for (int i = 0; i < m.nSpec(); i++) if (m.species[i].name == name) return i;
@@ -130,14 +138,48 @@ void read_field(const std::string& dir, Model& m)
     }
     else
         m.warnings.push_back("WARNING[001] no Van-der-Waals interactions");
-    reject_section(f, " bonds %d", "bonds");
+    // bond types: sys_init.cpp:289-314 + read_bond bonds.cpp:125-364.  Only constant bonds ('con con') are on the
+    // accelerated path; 'mut' / 'br' make the reference's use_bnd = 2 (variable bonds) and are refused.
+    m.bondTypes.clear(); m.angleTypes.clear();
+    if (seek_value(f, " bonds %d", &n) && n > 0)
+        for (int i = 1; i <= n; i++)
+        {
+            int id; char a[16], b[16], key[16];
+            if (std::fscanf(f, "%d %8s %8s %8s", &id, a, b, key) != 4) fail("ERROR[126] malformed bonds line " + std::to_string(i));
+            const int ia = species_by_name(m, a), ib = species_by_name(m, b);
+            if (ia < 0 || ib < 0) fail(std::string("ERROR[124]: Unknown species in bonds declaration: ") + a + " " + b);
+            const int type = bond_type_by_name(key);
+            if (!type) fail(std::string("ERROR[126]: Unknown potential type in bonds declaration: ") + key);
+            double p[5] = {0, 0, 0, 0, 0};
+            for (int k = 0; k < kBondNParam[type]; k++)
+                if (std::fscanf(f, " %lf", &p[k]) != 1) fail("ERROR[126] too few parameters in bonds line " + std::to_string(i));
+            for (int lim = 0; lim < 2; lim++)
+            {
+                if (std::fscanf(f, "%8s", key) != 1) fail("ERROR[501] truncated bonds line " + std::to_string(i));
+                if (std::strcmp(key, "con") != 0)
+                {
+                    if (std::strcmp(key, "mut") == 0 || (lim == 1 && std::strcmp(key, "br") == 0))
+                        fail("out of scope: variable bonds ('mut'/'br', use_bnd = 2) are not part of the accelerated hot path");
+                    fail(std::string(lim ? "ERROR[502]" : "ERROR[501]") + ": Unknown type of bond limit: " + key);
+                }
+            }
+            add_bond_type(m, ia, ib, type, p);
+        }
     reject_section(f, " evol_bonds %d", "evol_bonds");
     reject_section(f, " h-bonds %d", "h-bonds");
-    reject_section(f, " angles %d ", "angles");
+    // angle types: sys_init.cpp:411-427 + read_angle angles.cpp:78-128
+    if (seek_value(f, " angles %d ", &n) && n > 0)
+        for (int i = 1; i <= n; i++)
+        {
+            int id; char a[16], key[16]; double p0, p1;
+            if (std::fscanf(f, "%d %8s %8s %lf %lf", &id, a, key, &p0, &p1) != 5) fail("ERROR[012] malformed angles line " + std::to_string(i));
+            const int ia = species_by_name(m, a);
+            if (ia < 0) fail(std::string("ERROR[011]: Unknown species in angle declaration: ") + a);
+            if (std::strcmp(key, "hcos") != 0) fail(std::string("ERROR[012]: Unknown potential type in angle declaration: ") + key);
+            add_angle_type(m, ia, 1, p0, p1);
+        }
     reject_section(f, " angle_forming %d ", "angle_forming");
     reject_section(f, " linkage %d", "linkage");
-    reject_section(f, " bond_list %d", "bond_list");
-    reject_section(f, " angle_list %d", "angle_list");
     // radii: the integer after the keyword is ignored, nSpec lines follow (sys_init.cpp:468-480)
     if (seek_value(f, " radii %d", &n))
     {
@@ -150,6 +192,50 @@ void read_field(const std::string& dir, Model& m)
             if (j < 0) fail(std::string("ERROR[b018] wrong species(") + name + ") in radii section");
             if (std::fscanf(f, "%lf %lf %lf", &m.species[j].radA, &m.species[j].radB, &m.species[j].mxEng) != 3)
                 fail("ERROR[b018] malformed radii line");
+        }
+    }
+}
+
+// the 'bond_list' / 'angle_list' switches of field.txt and the files they name (read by the reference inside read_sim,
+// sys_init.cpp:626-673, i.e. after the atoms): bonds.txt 'N' + N x 'at1 at2 type' (bonds.cpp:25-110),
+// angles.txt 'N' + N x 'central lig1 lig2 type' (angles.cpp:22-60); atom indices are 0-based.
+void read_bonded_lists(const std::string& dir, Model& m)
+{
+    File file(dir + "/field.txt", "ERROR[409]");
+    int flag = 0;
+    if (seek_value(file.f, " bond_list %d", &flag))
+    {
+        FILE* g = std::fopen((dir + "/bonds.txt").c_str(), "r");
+        if (!g) m.warnings.push_back("WARNING[a001] bond list is used, but there is no such file. No bonds are downloaded");
+        else
+        {
+            int n = 0;
+            if (std::fscanf(g, "%d", &n) != 1 || n < 0) { std::fclose(g); fail("ERROR[121] malformed bonds.txt"); }
+            std::vector<int32_t> a(n), b(n), t(n);
+            for (int i = 0; i < n; i++)
+                if (std::fscanf(g, "%d %d %d", &a[i], &b[i], &t[i]) != 3) { std::fclose(g); fail("ERROR[121] truncated bonds.txt at line " + std::to_string(i)); }
+            std::fclose(g);
+            set_bond_list(m, n, a.data(), b.data(), t.data());
+        }
+    }
+    if (seek_value(file.f, " angle_list %d", &flag))
+    {
+        if (m.angleTypes.empty())
+            m.warnings.push_back("WARNING[b006] 'anlge_list' directive is ignored, because there are no angle type defintions");
+        else
+        {
+            FILE* g = std::fopen((dir + "/angles.txt").c_str(), "r");
+            if (!g) m.warnings.push_back("WARNING[a002] angle list is used, but there is no such file. No anlges are downloaded");
+            else
+            {
+                int n = 0;
+                if (std::fscanf(g, "%d", &n) != 1 || n < 0) { std::fclose(g); fail("ERROR[013] malformed angles.txt"); }
+                std::vector<int32_t> c(n), l1(n), l2(n), t(n);
+                for (int i = 0; i < n; i++)
+                    if (std::fscanf(g, "%d %d %d %d", &c[i], &l1[i], &l2[i], &t[i]) != 4) { std::fclose(g); fail("ERROR[013] truncated angles.txt at line " + std::to_string(i)); }
+                std::fclose(g);
+                set_angle_list(m, n, c.data(), l1.data(), l2.data(), t.data());
+            }
         }
     }
 }
@@ -325,6 +411,61 @@ double prob4(double x, double y, double theta)
 }
 
 }  // namespace
+
+void add_bond_type(Model& m, int spec1, int spec2, int type, const double p[5])
+{   // read_bond bonds.cpp:125-252: the unit factors applied there (E_scale, r_scale; const.h:39-41) are exactly 1.0
+    if (type < 1 || type > 5) fail("ERROR[126]: Unknown potential type in bonds declaration");
+    if (spec1 < 0 || spec1 >= m.nSpec() || spec2 < 0 || spec2 >= m.nSpec()) fail("ERROR[124]: Unknown species in bonds declaration");
+    BondType b; b.type = type; b.spec1 = spec1; b.spec2 = spec2;
+    for (int k = 0; k < 5; k++) b.p[k] = (k < kBondNParam[type]) ? p[k] : 0.0;
+    m.bondTypes.push_back(b);
+}
+
+void add_angle_type(Model& m, int central, int type, double k, double cos0)
+{   // read_angle angles.cpp:78-128
+    if (type != 1) fail("ERROR[012]: Unknown potential type in angle declaration");
+    if (central < 0 || central >= m.nSpec()) fail("ERROR[011]: Unknown species in angle declaration");
+    AngleType a; a.type = 1; a.central = central; a.k = k; a.cos0 = cos0;
+    m.angleTypes.push_back(a);
+}
+
+void set_bond_list(Model& m, int n, const int32_t* a, const int32_t* b, const int32_t* t)
+{
+    m.bondA.clear(); m.bondB.clear(); m.bondT.clear();
+    for (int i = 0; i < n; i++)
+    {
+        int at1 = a[i], at2 = b[i];
+        const int k = t[i];
+        if (k < 1 || k > (int)m.bondTypes.size()) fail("ERROR[121] unknown bond type " + std::to_string(k) + " in bond list, line " + std::to_string(i));
+        if (at1 < 0 || at1 >= m.nAt || at2 < 0 || at2 >= m.nAt) fail("ERROR[121] atom index out of range in bond list, line " + std::to_string(i));
+        const BondType& bt = m.bondTypes[k - 1];
+        if (bt.spec1 == m.types[at1])
+        {
+            if (bt.spec2 != m.types[at2]) fail("ERROR [121] incorrect type of 2th atom in bond (type: " + std::to_string(k) + ", line: " + std::to_string(i) + ")");
+        }
+        else if (bt.spec1 == m.types[at2])
+        {
+            if (bt.spec2 == m.types[at1]) std::swap(at1, at2);      // bonds.cpp:62-67
+            else fail("ERROR [122] incorrect type of 1th atom in bond (type: " + std::to_string(k) + ", line: " + std::to_string(i) + ")");
+        }
+        else fail("ERROR [123] incorrect type of atoms for bond type(" + std::to_string(k) + ") in bond list, line: " + std::to_string(i));
+        m.bondA.push_back(at1); m.bondB.push_back(at2); m.bondT.push_back(k);
+    }
+}
+
+void set_angle_list(Model& m, int n, const int32_t* c, const int32_t* l1, const int32_t* l2, const int32_t* t)
+{
+    m.angC.clear(); m.angL1.clear(); m.angL2.clear(); m.angT.clear();
+    for (int i = 0; i < n; i++)
+    {
+        if (t[i] < 1 || t[i] > (int)m.angleTypes.size()) fail("ERROR[013] wrong atom type number in angles.txt, line " + std::to_string(i));
+        if (c[i] < 0 || c[i] >= m.nAt || l1[i] < 0 || l1[i] >= m.nAt || l2[i] < 0 || l2[i] >= m.nAt)
+            fail("ERROR[013] atom index out of range in angle list, line " + std::to_string(i));
+        if (m.types[c[i]] != m.angleTypes[t[i] - 1].central)
+            fail("ERROR[014] wrong central atom type in angle list (" + std::to_string(i) + " postion)");
+        m.angC.push_back(c[i]); m.angL1.push_back(l1[i]); m.angL2.push_back(l2[i]); m.angT.push_back(t[i]);
+    }
+}
 
 PairPot prepare_vdw(int type, double rcut, const double p[5])
 {   // read_vdw: vdw.cpp:261-299 ; scale tables vdw.cpp:209-219 with r_scale = E_scale = 1 (const.h:38-41)
@@ -506,6 +647,7 @@ void init_md(const std::string& dir, Model& m)
 {
     read_field(dir, m);
     read_atoms_box(dir, m);
+    read_bonded_lists(dir, m);
     read_sim(dir, m);
     read_cuda(dir, m);
 }

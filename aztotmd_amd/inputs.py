@@ -85,6 +85,81 @@ def lj_case(ncell, a=5.735, jitter=0.15, seed=20240501, rc=8.5, dt=0.001, charge
     return case
 
 
+BOND_TYPES = {"harm": 1, "mors": 2, "pdn": 3, "buck": 4, "e612": 5}       # bonds.cpp:158-252
+BOND_NAMES = {v: k for k, v in BOND_TYPES.items()}
+BOND_NPARAM = {1: 2, 2: 4, 3: 5, 4: 3, 5: 5}
+
+
+def molecular_case(ngrid, a=3.6, seed=77, rc=7.5, dt=0.0005, charges=None, elec="none", r_real=7.5, alpha=0.35,
+                   vel_T=120.0, bond_mix=True, cell_list=None, quantize=True):
+    """Bent triatomic molecules L-C-L on a simple cubic grid of ngrid=(nx,ny,nz) sites with spacing a, random
+    orientation: the synthetic bonded input SURVEY Appendix G asks for ("next" row f2: constant bonds + hcos angles).
+
+    Species 0 = C (central), 1 = L (ligand).  Only C-C has a pair potential (LJ): the reference does not exclude
+    bonded pairs from the non-bonded loop (no exclusion list in pair_1 / pair_inter), so a C-L or L-L entry would
+    act inside the molecule too.  bond_mix cycles the five bond potentials of bonds.cpp:731-787 over the molecules,
+    tuned to the same minimum (r0 = 1.0) so that every branch of bond_iter is exercised; every second bond is listed
+    ligand-first to exercise the turn of read_bondlist (bonds.cpp:62-67).
+    """
+    nx, ny, nz = ngrid
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    cen = (np.stack([ii.ravel(), jj.ravel(), kk.ravel()], axis=1) + 0.5) * a
+    cen = cen + rng.uniform(-0.1, 0.1, size=cen.shape)
+    M = cen.shape[0]
+    box = np.array([nx * a, ny * a, nz * a], dtype=np.float64)
+    r0, cos0 = 1.0, -0.33
+    # random orthonormal pair (u, w) per molecule; ligands at angle acos(cos0) +- a little
+    u = rng.normal(size=(M, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+    w = rng.normal(size=(M, 3)); w -= (w * u).sum(1)[:, None] * u; w /= np.linalg.norm(w, axis=1)[:, None]
+    th = np.arccos(cos0) + rng.uniform(-0.15, 0.15, size=M)
+    l1 = cen + (r0 + rng.uniform(-0.05, 0.05, size=(M, 1))) * u
+    l2 = cen + (r0 + rng.uniform(-0.05, 0.05, size=(M, 1))) * (np.cos(th)[:, None] * u + np.sin(th)[:, None] * w)
+    pos = np.empty((3 * M, 3)); pos[0::3] = cen; pos[1::3] = l1; pos[2::3] = l2
+    pos = np.mod(pos, box)
+    if quantize:
+        pos = np.round(pos, 6); box = np.round(box, 6)
+    pos[pos >= box] = 0.0
+    types = np.tile(np.array([0, 1, 1], dtype=np.int32), M)
+    qC, qL = charges if charges else (0.0, 0.0)
+    species = [(15.999, qC), (1.008, qL)]
+    k_h = 30.0
+    bond_types = [(0, 1, 1, [k_h, r0])]
+    if bond_mix:
+        D, aa = 4.0, 2.0                               # Morse: k = 2 D a^2 = 32
+        bond_types += [(0, 1, 2, [D, aa, r0, 0.5]),
+                       (0, 1, 3, [D, aa, r0, 0.5, 0.002]),
+                       (1, 0, 4, [2.0e4, 0.1, 1.513]),   # listed L-C on purpose; buck minimum at r = 1.0 needs ro < 1/7
+                       (0, 1, 5, [2.0e4, 0.1, 1.1467, 0.2, 0.05])]
+    angle_types = [(0, 1, [3.0, cos0]), (0, 1, [1.5, -0.5])]
+    nbt = len(bond_types)
+    bonds, angles = [], []
+    for m in range(M):
+        c, a1, a2 = 3 * m, 3 * m + 1, 3 * m + 2
+        bonds.append((c, a1, 1 + (m % nbt)))
+        bonds.append((a2, c, 1 + ((m + 1) % nbt)))
+        angles.append((c, a1, a2, 1 + (m % 2)))
+    vel = np.zeros_like(pos)
+    if vel_T:
+        kB = 1.3806488E-23 / 1.60217733E-19
+        msc = 1.6605402E-27 / (1.60217733E-19 * 1e-24 / 1e-20)
+        mass = np.where(types == 0, species[0][0], species[1][0]) * msc
+        vel = rng.normal(size=pos.shape) * np.sqrt(kB * vel_T / mass)[:, None]
+        vel -= (vel * mass[:, None]).sum(0) / mass.sum()
+    return {
+        "box": box.tolist(), "dt": dt, "nsteps": 0,
+        "species": species, "names": ["C", "L"], "vdw": [(0, 0, VDW_TYPES["lnjs"], rc, [0.0067, 3.15])], "types": types,
+        "x": pos[:, 0].copy(), "y": pos[:, 1].copy(), "z": pos[:, 2].copy(),
+        "vx": vel[:, 0].copy(), "vy": vel[:, 1].copy(), "vz": vel[:, 2].copy(),
+        "elec_type": ELEC_TYPES[elec], "rReal": r_real if elec != "none" else 0.0, "alpha": alpha if elec != "none" else 0.0,
+        "T": 120.0, "tstat_type": 0, "nEq": 0, "freqEq": 1,
+        "use_clist": 1, "cell_list": cell_list if cell_list is not None else rc,
+        "center_box": 0, "init_forces": 1, "radii": None, "seed": 12345,
+        "bond_types": bond_types, "angle_types": angle_types,
+        "bonds": np.array(bonds, dtype=np.int32), "angles": np.array(angles, dtype=np.int32),
+    }
+
+
 def write_input_files(case, directory, stat=200):
     """Write atoms.xyz / field.txt / control.txt / cuda.txt for `case` (reference grammar)."""
     os.makedirs(directory, exist_ok=True)
@@ -106,6 +181,19 @@ def write_input_files(case, directory, stat=200):
         for a, b, t, rc, p in case["vdw"]:
             ps = "\t".join(repr(float(v)) for v in list(p)[:VDW_NPARAM[t]])
             f.write("%s\t%s\t%s\t%r\t%s\n" % (names[a], names[b], VDW_NAMES[t], float(rc), ps))
+        if case.get("bond_types"):
+            f.write("bonds %d\n" % len(case["bond_types"]))
+            for i, (a, b, t, p) in enumerate(case["bond_types"]):
+                ps = "\t".join(repr(float(v)) for v in list(p)[:BOND_NPARAM[t]])
+                f.write("%d\t%s\t%s\t%s\t%s\tcon\tcon\n" % (i + 1, names[a], names[b], BOND_NAMES[t], ps))
+        if case.get("angle_types"):
+            f.write("angles %d\n" % len(case["angle_types"]))
+            for i, (c, t, p) in enumerate(case["angle_types"]):
+                f.write("%d\t%s\thcos\t%r\t%r\n" % (i + 1, names[c], float(p[0]), float(p[1])))
+        if case.get("bonds") is not None and len(case["bonds"]):
+            f.write("bond_list 1\n")
+        if case.get("angles") is not None and len(case["angles"]):
+            f.write("angle_list 1\n")
         if case.get("radii"):
             f.write("radii %d\n" % len(case["species"]))
             for nm, r in zip(names, case["radii"]):
@@ -130,6 +218,14 @@ def write_input_files(case, directory, stat=200):
             f.write("elec\t%s\t%r\t%r\n" % (et, case["rReal"], case["alpha"]))
         f.write("rdf\t8.0\t0.02\t1000000\t1000000\tnucl\n")
         f.write("stat\t%d\n" % stat)
+    if case.get("bonds") is not None and len(case["bonds"]):
+        with open(os.path.join(directory, "bonds.txt"), "w") as f:       # read_bondlist, bonds.cpp:25-110
+            f.write("%d\n" % len(case["bonds"]))
+            f.writelines("%d %d %d\n" % tuple(int(v) for v in row) for row in case["bonds"])
+    if case.get("angles") is not None and len(case["angles"]):
+        with open(os.path.join(directory, "angles.txt"), "w") as f:      # read_anglelist, angles.cpp:22-60
+            f.write("%d\n" % len(case["angles"]))
+            f.writelines("%d %d %d %d\n" % tuple(int(v) for v in row) for row in case["angles"])
     with open(os.path.join(directory, "cuda.txt"), "w") as f:
         f.write("nstep stat 50\nnthread a 16\nnthread b 32\n")
     return directory

@@ -87,6 +87,36 @@ typedef struct
     aztot_control control;
 } aztot_system;
 
+/* bonded terms ("next" row: constant bonds + harmonic-cosine angles) */
+enum { AZTOT_BOND_HARM = 1, AZTOT_BOND_MORSE = 2, AZTOT_BOND_PEDONE = 3, AZTOT_BOND_BUCK = 4, AZTOT_BOND_E612 = 5 };   /* bonds.cpp:158-252 */
+enum { AZTOT_ANGLE_HCOS = 1 };                                                                                      /* angles.cpp:111 */
+
+/* one line of the 'bonds' section of field.txt (read_bond, bonds.cpp:125-364) with the 'con con' tail:
+   harm k r0 | mors D a r0 C | pdn D a r0 C E | buck A ro C | e612 A ro C D F */
+typedef struct
+{
+    int32_t spec_a, spec_b, type;
+    double p[5];
+} aztot_bond_type;
+
+/* one line of the 'angles' section of field.txt (read_angle, angles.cpp:78-128): centralSpec hcos k cos0 */
+typedef struct
+{
+    int32_t central, type;
+    double k, cos0;
+} aztot_angle_type;
+
+/* type tables + the contents of bonds.txt (read_bondlist, bonds.cpp:25-110) and angles.txt (read_anglelist,
+   angles.cpp:22-60).  Atom indices are 0-based; type ids are 1-based as in the files (id k = entry k-1 of the table). */
+typedef struct
+{
+    int32_t n_bond_types, n_angle_types, n_bonds, n_angles;
+    const aztot_bond_type *bond_types;
+    const aztot_angle_type *angle_types;
+    const int32_t *bond_a, *bond_b, *bond_type;
+    const int32_t *angle_c, *angle_l1, *angle_l2, *angle_type;
+} aztot_bonded;
+
 /* run-time switches that replace the reference's compile-time defines.h and its two mains' differences */
 typedef struct
 {
@@ -115,6 +145,7 @@ typedef struct
     int64_t pairs_dropped;       /* pairs skipped by the |f|^2 > 1e10 rule (integrators.cpp:170) */
     int64_t n_cells;
     double nose_chit, nose_conint;  /* Nose-Hoover friction and conserved-quantity integral (temperature.h:24-25) */
+    double engBond, engAngle;    /* exec_bondlist bonds.cpp:1218, exec_anglelist angles.cpp:240; both are part of engTot */
 } aztot_stats;
 
 /* host copy of the per-atom state, fp64 SoA, in ORIGINAL atom order (id order); any pointer may be NULL */
@@ -129,6 +160,9 @@ typedef struct
 /* reads atoms.xyz, field.txt, control.txt, cuda.txt from `dir` (reference: from the cwd) */
 int aztot_init_md(const char *dir, aztot_model **out);
 int aztot_model_create(const aztot_system *sys, aztot_model **out);
+/* attach bonded terms to a model made by aztot_model_create (aztot_init_md reads them from field.txt + bonds.txt +
+   angles.txt itself); replaces sys_init.cpp:289-314,411-427,626-673.  Must precede aztot_init_device. */
+int aztot_model_set_bonded(aztot_model *m, const aztot_bonded *b);
 /* string-keyed read-out of parsed/derived values as doubles; returns the number of values written
    (or needed, if cap is too small), negative on unknown key.  Keys: see aztotmd_amd/csrc/capi.cpp */
 int aztot_model_query(const aztot_model *m, const char *key, double *out, int cap);

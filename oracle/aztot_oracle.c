@@ -52,6 +52,8 @@ enum { TSTAT_NONE = 0, TSTAT_NOSE = 1, TSTAT_RADI = 2 };                        
 #define ORC_NUVECT 3072                                                                                                /* cuTemp.h:4 */
 
 typedef struct { int type; int use_radii; double p0, p1, p2, p3, p4, r2cut; } orc_vdw;
+typedef struct { int type, spec1, spec2; double p0, p1, p2, p3, p4; } orc_bond;      /* Bond, dataStruct.h:321-339 (constant bonds only) */
+typedef struct { int type, central; double p0, p1; } orc_angle;                      /* Angle, dataStruct.h:341-346 */
 
 typedef struct
 {
@@ -84,6 +86,11 @@ typedef struct
     /* radiative thermostat state (cuStruct.h:250-255,335-339,384-385) */
     double *U, *rad, *photons; double *uvx, *uvy, *uvz; int *pid; uint64_t seed;
     double revLight, radiate_frac, radiate_thr, numPi;
+    /* bonded terms: Field fields dataStruct.h:389-410 ; index 0 of both type tables is the reserved 'none' */
+    int nBdata, nAdata, nBonds, nAngles;
+    orc_bond *bdata; orc_angle *adata;
+    int *at1, *at2, *bTypes, *centrs, *lig1, *lig2, *angTypes;
+    double engBond, engAngle;
 } orc_sys;
 
 /* ---------------------------------------------------------------- counter-based RNG (ours: SURVEY C-11/E) */
@@ -140,6 +147,8 @@ void orc_free(orc_sys *s)
     free(s->charged); free(s->frozen); free(s->vdw);
     free(s->clist); free(s->chead); free(s->neig);
     free(s->photons); free(s->uvx); free(s->uvy); free(s->uvz);
+    free(s->bdata); free(s->adata); free(s->at1); free(s->at2); free(s->bTypes);
+    free(s->centrs); free(s->lig1); free(s->lig2); free(s->angTypes);
     free(s);
 }
 
@@ -497,7 +506,7 @@ static void clear_force(orc_sys *s)
     }
 }
 
-static void reset_chars(orc_sys *s) { s->engVdW = 0.0; s->engElec3 = 0.0; s->engElecField = 0.0; s->engTemp = 0.0; }   /* integrators.cpp:42-60 */
+static void reset_chars(orc_sys *s) { s->engVdW = 0.0; s->engElec3 = 0.0; s->engElecField = 0.0; s->engTemp = 0.0; s->engBond = 0.0; s->engAngle = 0.0; }   /* integrators.cpp:42-60 */
 
 static void pair_inter(orc_sys *s, int i, int j)
 {   /* pair_inter: integrators.cpp:139-185 ; sqr_distance_proj box.cpp:327-335 */
@@ -610,9 +619,9 @@ static void integrate2(orc_sys *s, int tScale)
 }
 
 static void calc_chars(orc_sys *s)
-{   /* calc_chars: integrators.cpp:63-73 (engElec1/2, engBond, engAngle, engOwn are 0 on this path) */
+{   /* calc_chars: integrators.cpp:63-73 (engElec1/2 and engOwn are 0 on this path) */
     s->TempNow = 2.0 * s->engKin * (double)(1.0 / s->degFree) * (1.0 / c_kB());
-    s->engTot = s->engElecField + s->engVdW + s->engElec3 + s->engKin;
+    s->engTot = s->engElecField + s->engVdW + s->engElec3 + s->engKin + s->engBond + s->engAngle;
 }
 
 /* ---------------------------------------------------------------- radiative thermostat (cuTemp.cu, fp64 restatement) */
@@ -689,13 +698,185 @@ static void tstat_radi(orc_sys *s, uint64_t step)
     }
 }
 
+/* ---------------------------------------------------------------- bonds.cpp / angles.cpp (constant bonds, hcos angles) */
+/* read_bond: bonds.cpp:125-364.  n types, ids 1..n (index 0 reserved, sys_init.cpp:293-295).  type: 1 harm (k r0),
+   2 mors (D a r0 C), 3 pdn (D a r0 C E), 4 buck (A ro C), 5 e612 (A ro C D F).  All unit factors of const.h:39-41
+   are exactly 1.0 (E_scale, r_scale), so the stored parameters equal the raw ones bit for bit; only the
+   'con con' tail (mnEx = mxEx = 0) is in scope. */
+int orc_set_bond_types(orc_sys *s, int n, const int *spec1, const int *spec2, const int *type, const double *p)
+{
+    free(s->bdata);
+    s->nBdata = n + 1;
+    s->bdata = (orc_bond *)calloc((size_t)n + 1, sizeof(orc_bond));
+    for (int i = 1; i <= n; i++)
+    {
+        orc_bond *b = &s->bdata[i];
+        if (type[i - 1] < 1 || type[i - 1] > 5) return -1;
+        if (spec1[i - 1] < 0 || spec1[i - 1] >= s->nSpec || spec2[i - 1] < 0 || spec2[i - 1] >= s->nSpec) return -2;   /* ERROR[124] */
+        b->type = type[i - 1]; b->spec1 = spec1[i - 1]; b->spec2 = spec2[i - 1];
+        const double *q = p + 5 * (size_t)(i - 1);
+        b->p0 = q[0]; b->p1 = q[1]; b->p2 = q[2]; b->p3 = q[3]; b->p4 = q[4];
+    }
+    return 0;
+}
+
+/* read_angle: angles.cpp:78-128 ('hcos' k cos0 ; ids 1..n, index 0 reserved sys_init.cpp:414-420) */
+int orc_set_angle_types(orc_sys *s, int n, const int *central, const int *type, const double *p)
+{
+    free(s->adata);
+    s->nAdata = n + 1;
+    s->adata = (orc_angle *)calloc((size_t)n + 1, sizeof(orc_angle));
+    for (int i = 1; i <= n; i++)
+    {
+        if (type[i - 1] != 1) return -1;                                  /* ERROR[012] */
+        if (central[i - 1] < 0 || central[i - 1] >= s->nSpec) return -2;  /* ERROR[011] */
+        s->adata[i].type = 1; s->adata[i].central = central[i - 1];
+        s->adata[i].p0 = p[2 * (size_t)(i - 1)]; s->adata[i].p1 = p[2 * (size_t)(i - 1) + 1];
+    }
+    return 0;
+}
+
+/* read_bondlist: bonds.cpp:25-110 (bonds.txt: 'N' then 'at1 at2 type', atoms 0-based).  The pair is turned so that
+   at1 carries the type's spec1 (:51-79); a species mismatch is ERROR[121..123] -> negative return here. */
+int orc_set_bond_list(orc_sys *s, int n, const int *a, const int *b, const int *t)
+{
+    free(s->at1); free(s->at2); free(s->bTypes);
+    s->nBonds = n;
+    s->at1 = (int *)malloc(sizeof(int) * (size_t)(n + 1)); s->at2 = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    s->bTypes = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    for (int i = 0; i < n; i++)
+    {
+        int i1 = a[i], i2 = b[i], k = t[i];
+        if (k < 1 || k >= s->nBdata || i1 < 0 || i1 >= s->N || i2 < 0 || i2 >= s->N) return -4;
+        const orc_bond *bt = &s->bdata[k];
+        if (bt->spec1 == s->types[i1]) { if (bt->spec2 != s->types[i2]) return -1; }
+        else if (bt->spec1 == s->types[i2]) { if (bt->spec2 == s->types[i1]) { int w = i1; i1 = i2; i2 = w; } else return -2; }
+        else return -3;
+        s->at1[i] = i1; s->at2[i] = i2; s->bTypes[i] = k;
+    }
+    return 0;
+}
+
+/* read_anglelist: angles.cpp:22-60 (angles.txt: 'N' then 'central lig1 lig2 type') */
+int orc_set_angle_list(orc_sys *s, int n, const int *c, const int *l1, const int *l2, const int *t)
+{
+    free(s->centrs); free(s->lig1); free(s->lig2); free(s->angTypes);
+    s->nAngles = n;
+    s->centrs = (int *)malloc(sizeof(int) * (size_t)(n + 1)); s->lig1 = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    s->lig2 = (int *)malloc(sizeof(int) * (size_t)(n + 1)); s->angTypes = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    for (int i = 0; i < n; i++)
+    {
+        if (t[i] < 1 || t[i] >= s->nAdata) return -1;                                    /* ERROR[013] */
+        if (c[i] < 0 || c[i] >= s->N || l1[i] < 0 || l1[i] >= s->N || l2[i] < 0 || l2[i] >= s->N) return -4;
+        if (s->types[c[i]] != s->adata[t[i]].central) return -2;                         /* ERROR[014] */
+        s->centrs[i] = c[i]; s->lig1[i] = l1[i]; s->lig2[i] = l2[i]; s->angTypes[i] = t[i];
+    }
+    return 0;
+}
+
+static double bond_iter(double r2, const orc_bond *b, double *eng)
+{   /* bond_iter: bonds.cpp:731-787 ; returns -(1/r) dU/dr */
+    double r, x, y, irn, ir2;
+    switch (b->type)
+    {
+    case 1:
+        r = sqrt(r2); x = r - b->p1;
+        *eng += 0.5 * b->p0 * x * x;
+        return -b->p0 / r * x;
+    case 2:
+        r = sqrt(r2); x = r - b->p2; x = exp(-b->p1 * x); y = 1 - x;
+        *eng += b->p0 * y * y - b->p3;
+        return -2.0 * b->p0 * b->p1 * x * y / r;
+    case 3:
+        r = sqrt(r2); x = r - b->p2; x = exp(-b->p1 * x); y = 1 - x;
+        ir2 = 1.0 / r2; irn = ir2 * ir2; irn = irn * irn * irn;
+        *eng += b->p0 * y * y - b->p3 - b->p4 * irn;
+        return -2.0 * b->p0 * b->p1 * x * y / r - 12.0 * b->p4 * irn * ir2;
+    case 4:
+        r = sqrt(r2); ir2 = 1.0 / r2; irn = ir2 * ir2;
+        *eng += b->p0 * exp(-r / b->p1) - b->p2 * irn * ir2;
+        return b->p0 * exp(-r / b->p1) / r / b->p1 - 6.0 * b->p2 * irn * irn;
+    case 5:
+        r = sqrt(r2); ir2 = 1.0 / r2; irn = ir2 * ir2;
+        *eng += b->p0 * exp(-r / b->p1) - b->p2 * irn * ir2 - b->p3 * irn * irn - b->p4 * irn * irn * irn;
+        return b->p0 * exp(-r / b->p1) / r / b->p1 - 6.0 * b->p2 * irn * irn - 8.0 * b->p3 * irn * irn * ir2
+               - 12.0 * b->p4 * irn * irn * irn * ir2;
+    }
+    return 0.0;
+}
+
+static void exec_bondlist(orc_sys *s)
+{   /* exec_bondlist: bonds.cpp:1069-1218 with mnEx = mxEx = 0 (constant bonds) */
+    double eng = 0.0;
+    for (int i = 0; i < s->nBonds; i++)
+    {
+        int ia = s->at1[i], ja = s->at2[i];
+        double dx = s->x[ia] - s->x[ja], dy = s->y[ia] - s->y[ja], dz = s->z[ia] - s->z[ja];   /* sqr_distance_proj, box.cpp:327-335 */
+        delta_periodic(s, &dx, &dy, &dz);
+        double r2 = dx * dx + dy * dy + dz * dz;
+        double f = bond_iter(r2, &s->bdata[s->bTypes[i]], &eng);
+        s->fx[ia] += f * dx; s->fx[ja] -= f * dx;
+        s->fy[ia] += f * dy; s->fy[ja] -= f * dy;
+        s->fz[ia] += f * dz; s->fz[ja] -= f * dz;
+    }
+    s->engBond = eng;
+}
+
+static void exec_anglelist(orc_sys *s)
+{   /* angle_iter + exec_anglelist: angles.cpp:179-242 */
+    double eng = 0.0;
+    for (int i = 0; i < s->nAngles; i++)
+    {
+        int c = s->centrs[i], l1 = s->lig1[i], l2 = s->lig2[i];
+        const orc_angle *ang = &s->adata[s->angTypes[i]];
+        double k = ang->p0, cos0 = ang->p1;
+        double xij = s->x[l1] - s->x[c], yij = s->y[l1] - s->y[c], zij = s->z[l1] - s->z[c];
+        delta_periodic(s, &xij, &yij, &zij);
+        double r2ij = xij * xij + yij * yij + zij * zij;
+        double rij = sqrt(r2ij);
+        double xik = s->x[l2] - s->x[c], yik = s->y[l2] - s->y[c], zik = s->z[l2] - s->z[c];
+        delta_periodic(s, &xik, &yik, &zik);
+        double r2ik = xik * xik + yik * yik + zik * zik;
+        double rik = sqrt(r2ik);
+        double cos_th = (xij * xik + yij * yik + zij * zik) / rij / rik;
+        double dCos = cos_th - cos0;
+        double c1 = -k * dCos;
+        double c2 = 1.0 / rij / rik;
+        s->fx[c] += -c1 * (xik * c2 + xij * c2 - cos_th * (xij / r2ij + xik / r2ik));
+        s->fy[c] += -c1 * (yik * c2 + yij * c2 - cos_th * (yij / r2ij + yik / r2ik));
+        s->fz[c] += -c1 * (zik * c2 + zij * c2 - cos_th * (zij / r2ij + zik / r2ik));
+        s->fx[l1] += c1 * (xik * c2 - cos_th * xij / r2ij);
+        s->fy[l1] += c1 * (yik * c2 - cos_th * yij / r2ij);
+        s->fz[l1] += c1 * (zik * c2 - cos_th * zij / r2ij);
+        s->fx[l2] += c1 * (xij * c2 - cos_th * xik / r2ik);
+        s->fy[l2] += c1 * (yij * c2 - cos_th * yik / r2ik);
+        s->fz[l2] += c1 * (zij * c2 - cos_th * zik / r2ik);
+        eng += 0.5 * k * dCos * dCos;
+    }
+    s->engAngle = eng;
+}
+
+/* single-term known answers for the tests */
+double orc_bond_pair(int type, const double *p, double r2, double *eng_out)
+{
+    orc_bond b; b.type = type; b.spec1 = b.spec2 = 0; b.p0 = p[0]; b.p1 = p[1]; b.p2 = p[2]; b.p3 = p[3]; b.p4 = p[4];
+    *eng_out = 0.0;
+    return bond_iter(r2, &b, eng_out);
+}
+
 /* ---------------------------------------------------------------- public stepping API */
-/* mode 0: all pairs (integrators.cpp:278), 1: linked cells (integrators.cpp:238; falls back to 0 if no table) */
+/* mode 0: all pairs (integrators.cpp:278), 1: linked cells (integrators.cpp:238; falls back to 0 if no table);
+   mode | 2: without the bonded terms (the state init_serial leaves, sys_init.cpp:1181-1184: all_pairs only) */
 void orc_forces(orc_sys *s, int mode)
 {
     reset_chars(s);
     clear_force(s);
-    if (mode == 1 && s->nHead) { build_clist(s); cell_list_forces(s); } else all_pairs(s);
+    if ((mode & 1) && s->nHead) { build_clist(s); cell_list_forces(s); } else all_pairs(s);
+    if (!(mode & 2))
+    {
+        if (s->nBonds) exec_bondlist(s);                                   /* main.cpp:101-104 */
+        if (s->nAngles) exec_anglelist(s);
+    }
 }
 
 void orc_step(orc_sys *s, int nsteps)
@@ -707,6 +888,8 @@ void orc_step(orc_sys *s, int nsteps)
         integrate1(s);
         clear_force(s);
         if (s->nHead) cell_list_forces(s); else all_pairs(s);
+        if (s->nBonds) exec_bondlist(s);                                   /* main.cpp:101-104 */
+        if (s->nAngles) exec_anglelist(s);
         int tScale = (s->iStep <= s->nEq) && s->freqEq > 0 && ((s->iStep % s->freqEq) == 0);   /* main.cpp:110-119 */
         integrate2(s, tScale);
         if (s->tstat_type == TSTAT_RADI) tstat_radi(s, (uint64_t)s->iStep);
@@ -736,13 +919,13 @@ void orc_set_thermo(orc_sys *s, const double *U, const double *rad)
 { size_t nb = 8 * (size_t)s->N; if (U) memcpy(s->U, U, nb); if (rad) memcpy(s->rad, rad, nb); }
 const double *orc_photons(const orc_sys *s) { return s->photons; }
 
-/* out[0..17]: engVdW, engElec3, engKin, engTot, engElecField, engTemp, Temp, mom[6], nDropped, iStep, tKin */
+/* out[0..19]: engVdW, engElec3, engKin, engTot, engElecField, engTemp, Temp, mom[6], nDropped, iStep, tKin, chit, conint, engBond, engAngle */
 void orc_get_stats(const orc_sys *s, double *out)
 {
     out[0] = s->engVdW; out[1] = s->engElec3; out[2] = s->engKin; out[3] = s->engTot; out[4] = s->engElecField;
     out[5] = s->engTemp; out[6] = s->TempNow;
     for (int k = 0; k < 6; k++) out[7 + k] = s->mom[k];
     out[13] = (double)s->nDropped; out[14] = (double)s->iStep; out[15] = s->tKin;
-    out[16] = s->chit; out[17] = s->conint;
+    out[16] = s->chit; out[17] = s->conint; out[18] = s->engBond; out[19] = s->engAngle;
 }
 void orc_get_cross(const orc_sys *s, long long *out) { for (int k = 0; k < 6; k++) out[k] = s->cross[k]; }

@@ -15,8 +15,12 @@ Layout (little endian):
   nSpec x (f64 mass_amu, f64 charge)
   nVdw  x (i32 a, i32 b, i32 type, f64 rc, f64 p[5])
   i32 type[N] ; f64 x[N], y[N], z[N], vx[N], vy[N], vz[N]
+  (version >= 3) bonded section - field.txt 'bonds'/'angles' + bonds.txt / angles.txt:
+  i32 nBondTypes x (i32 spec1, spec2, type(1 harm 2 mors 3 pdn 4 buck 5 e612), f64 p[5])
+  i32 nAngleTypes x (i32 central, type(1 hcos), f64 k, cos0)
+  i32 nBonds x (i32 at1, at2, type 1-based) ; i32 nAngles x (i32 central, lig1, lig2, type 1-based)
 
-Output of ref_driver: i32 N, nHead, cn(packed), ndump ; per dump: i32 step, f64 e[12], 9 x f64[N].
+Output of ref_driver: i32 N, nHead, cn(packed), ndump ; per dump: i32 step, f64 e[14], 9 x f64[N].
 """
 import struct
 import numpy as np
@@ -24,7 +28,8 @@ import numpy as np
 VDW_TYPES = {"lnjs": 1, "buck": 2, "p746": 3, "bmhs": 4, "elin": 5, "einv": 6, "surk": 7}
 ELEC_TYPES = {"none": 0, "dir": 1, "pme": 2, "fenn": 3}
 ENERGY_FIELDS = ("engVdW", "engElec3", "engKin", "engTot", "engElecField", "Temp",
-                 "momXn", "momXp", "momYn", "momYp", "momZn", "momZp")
+                 "momXn", "momXp", "momYn", "momYp", "momZn", "momZp", "engBond", "engAngle")
+BOND_TYPES = {"harm": 1, "mors": 2, "pdn": 3, "buck": 4, "e612": 5}
 
 
 def write_case(path, case):
@@ -34,7 +39,7 @@ def write_case(path, case):
     dump = list(case.get("dump", [0]))
     with open(path, "wb") as f:
         f.write(b"AZTC")
-        f.write(struct.pack("<i", 2))
+        f.write(struct.pack("<i", 3))
         f.write(struct.pack("<iii", N, len(species), len(vdw)))
         f.write(struct.pack("<ddd", *case["box"]))
         f.write(struct.pack("<d", case["dt"]))
@@ -53,6 +58,20 @@ def write_case(path, case):
         f.write(np.asarray(case["types"], dtype="<i4").tobytes())
         for k in ("x", "y", "z", "vx", "vy", "vz"):
             f.write(np.ascontiguousarray(case[k], dtype="<f8").tobytes())
+        bt, at = case.get("bond_types") or [], case.get("angle_types") or []
+        f.write(struct.pack("<i", len(bt)))
+        for s1, s2, t, p in bt:
+            p = list(p) + [0.0] * (5 - len(p))
+            f.write(struct.pack("<iii5d", s1, s2, t, *p))
+        f.write(struct.pack("<i", len(at)))
+        for c, t, p in at:
+            f.write(struct.pack("<iidd", c, t, p[0], p[1]))
+        bonds = np.asarray(case.get("bonds") if case.get("bonds") is not None else [], dtype="<i4").reshape(-1, 3)
+        angles = np.asarray(case.get("angles") if case.get("angles") is not None else [], dtype="<i4").reshape(-1, 4)
+        f.write(struct.pack("<i", len(bonds)))
+        f.write(np.ascontiguousarray(bonds).tobytes())
+        f.write(struct.pack("<i", len(angles)))
+        f.write(np.ascontiguousarray(angles).tobytes())
 
 
 def read_ref_output(path):
@@ -64,7 +83,7 @@ def read_ref_output(path):
             if len(hdr) < 4:
                 break
             (step,) = struct.unpack("<i", hdr)
-            e = struct.unpack("<12d", f.read(96))
+            e = struct.unpack("<14d", f.read(112))
             d = dict(zip(ENERGY_FIELDS, e))
             for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
                 d[k] = np.frombuffer(f.read(8 * N), dtype="<f8").copy()

@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 STAT_FIELDS = ("engVdW", "engElec3", "engKin", "engTot", "engElecField", "engTemp", "Temp",
-               "momXn", "momXp", "momYn", "momYp", "momZn", "momZp", "nDropped", "iStep", "tKin", "chit", "conint")
+               "momXn", "momXp", "momYn", "momYp", "momZn", "momZp", "nDropped", "iStep", "tKin", "chit", "conint",
+               "engBond", "engAngle")
 
 
 def build(force=False):
@@ -61,6 +62,12 @@ def lib():
         L.orc_set_forces.argtypes = [C.c_void_p] + [dp] * 3
         L.orc_set_thermo.argtypes = [C.c_void_p] + [dp] * 2
         L.orc_get_stats.argtypes = [C.c_void_p, dp]
+        L.orc_set_bond_types.argtypes = [C.c_void_p, C.c_int, ip, ip, ip, dp]
+        L.orc_set_angle_types.argtypes = [C.c_void_p, C.c_int, ip, ip, dp]
+        L.orc_set_bond_list.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        L.orc_set_angle_list.argtypes = [C.c_void_p, C.c_int, ip, ip, ip, ip]
+        L.orc_bond_pair.argtypes = [C.c_int, dp, C.c_double, dp]
+        L.orc_bond_pair.restype = C.c_double
         L.orc_get_cross.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.orc_cells.argtypes = [C.c_void_p, ip]
         L.orc_cells.restype = C.c_int
@@ -118,8 +125,39 @@ class Oracle:
                           case.get("Uz", 0.0), case.get("seed", 12345))
         L.orc_set_nose(self.h, case.get("tau", 0.0))
         L.orc_prepare(self.h)
+        self._set_bonded(case)
         if case.get("center_box", 0):
             L.orc_center_box(self.h)
+
+    def _set_bonded(self, case):
+        L = self.L
+        i4 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        ipt = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        bt, at = case.get("bond_types") or [], case.get("angle_types") or []
+        if bt:
+            s1, s2, tp = i4([b[0] for b in bt]), i4([b[1] for b in bt]), i4([b[2] for b in bt])
+            pp = _f8([list(b[3]) + [0.0] * (5 - len(b[3])) for b in bt])
+            if L.orc_set_bond_types(self.h, len(bt), ipt(s1), ipt(s2), ipt(tp), _dp(pp)):
+                raise ValueError("bad bond type table")
+        if at:
+            ce, tp = i4([a[0] for a in at]), i4([a[1] for a in at])
+            pp = _f8([list(a[2]) for a in at])
+            if L.orc_set_angle_types(self.h, len(at), ipt(ce), ipt(tp), _dp(pp)):
+                raise ValueError("bad angle type table")
+        bonds = case.get("bonds")
+        if bonds is not None and len(bonds):
+            b = i4(bonds).reshape(-1, 3)
+            cols = [i4(b[:, k]) for k in range(3)]
+            rc = L.orc_set_bond_list(self.h, len(b), *[ipt(c) for c in cols])
+            if rc:
+                raise ValueError("bond list rejected (%d): species do not match the bond type" % rc)
+        angles = case.get("angles")
+        if angles is not None and len(angles):
+            a = i4(angles).reshape(-1, 4)
+            cols = [i4(a[:, k]) for k in range(4)]
+            rc = L.orc_set_angle_list(self.h, len(a), *[ipt(c) for c in cols])
+            if rc:
+                raise ValueError("angle list rejected (%d)" % rc)
 
     def close(self):
         if self.h:
@@ -144,7 +182,7 @@ class Oracle:
         return out
 
     def stats(self):
-        s = np.empty(18)
+        s = np.empty(20)
         self.L.orc_get_stats(self.h, _dp(s))
         d = dict(zip(STAT_FIELDS, s.tolist()))
         cr = (C.c_longlong * 6)()
@@ -180,6 +218,14 @@ def vdw_pair(type_id, rc, params, r2, radi=0.0, radj=0.0):
     p = _f8(list(params) + [0.0] * (5 - len(params)))
     e = C.c_double(0.0)
     f = lib().orc_vdw_pair(type_id, rc, _dp(p), r2, radi, radj, C.byref(e))
+    return f, e.value
+
+
+def bond_pair(type_id, params, r2):
+    """(-(1/r) dU/dr, U) of one bond potential (bond_iter, bonds.cpp:731-787)."""
+    p = _f8(list(params) + [0.0] * (5 - len(params)))
+    e = C.c_double(0.0)
+    f = lib().orc_bond_pair(type_id, _dp(p), r2, C.byref(e))
     return f, e.value
 
 

@@ -17,6 +17,8 @@ import re
 
 VDW_TYPES = {"lnjs": 1, "buck": 2, "p746": 3, "bmhs": 4, "elin": 5, "einv": 6, "surk": 7}
 VDW_NPARAM = {1: 2, 2: 3, 3: 3, 4: 5, 5: 3, 6: 3, 7: 4}
+BOND_TYPES = {"harm": 1, "mors": 2, "pdn": 3, "buck": 4, "e612": 5}
+BOND_NPARAM = {1: 2, 2: 4, 3: 5, 4: 3, 5: 5}
 
 # const.h:17-49
 _E_SI, _Q_SI, _KB_SI, _E0_SI, _AMU_SI = 1.60217733E-19, 1.60217657E-19, 1.3806488E-23, 8.854187817E-12, 1.6605402E-27
@@ -171,6 +173,25 @@ def parse_dir(directory, with_atoms=True):
         vdw[ia][ib] = pp
         if t != 7:
             vdw[ib][ia] = pp
+    # bonds / angles sections (sys_init.cpp:289-314,411-427 ; read_bond bonds.cpp:125-364 ; read_angle angles.cpp:78-128)
+    bond_types, angle_types = [], []
+    for _ in range(f.find(" bonds %d") or 0):
+        f.next("d")
+        a, b, key = f.next("s"), f.next("s"), f.next("s")
+        t = BOND_TYPES[key]
+        p = [f.next("f") for _ in range(BOND_NPARAM[t])]
+        tail = [f.next("s"), f.next("s")]
+        if tail != ["con", "con"]:
+            raise ValueError("out of scope: variable bonds")
+        bond_types.append({"type": t, "spec1": names.index(a), "spec2": names.index(b), "p": p + [0.0] * (5 - len(p))})
+    for _ in range(f.find(" angles %d ") or 0):
+        f.next("d")
+        a, key = f.next("s"), f.next("s")
+        if key != "hcos":
+            raise ValueError("ERROR[012]")
+        angle_types.append({"type": 1, "central": names.index(a), "k": f.next("f"), "cos0": f.next("f")})
+    out.update(bond_types=bond_types, angle_types=angle_types, bond_list=f.find(" bond_list %d") is not None,
+               angle_list=f.find(" angle_list %d") is not None)
     if f.find(" radii %d") is not None:
         for _ in range(ns):
             nm = f.next("s")
@@ -195,6 +216,23 @@ def parse_dir(directory, with_atoms=True):
         for t in types:
             species[t]["number"] += 1
         out.update(types=types, x=xs, y=ys, z=zs)
+        # bonds.txt / angles.txt (read_bondlist bonds.cpp:25-110 with its turn ; read_anglelist angles.cpp:22-60)
+        bonds, angles = [], []
+        if out["bond_list"] and os.path.exists(os.path.join(directory, "bonds.txt")):
+            b = Scanner(_read(os.path.join(directory, "bonds.txt")))
+            for _ in range(b.next("d")):
+                a1, a2, k = b.next("d"), b.next("d"), b.next("d")
+                bt = bond_types[k - 1]
+                if bt["spec1"] != types[a1]:
+                    a1, a2 = a2, a1
+                if (bt["spec1"], bt["spec2"]) != (types[a1], types[a2]):
+                    raise ValueError("ERROR [121-123] species do not match the bond type")
+                bonds.append((a1, a2, k))
+        if out["angle_list"] and angle_types and os.path.exists(os.path.join(directory, "angles.txt")):
+            b = Scanner(_read(os.path.join(directory, "angles.txt")))
+            for _ in range(b.next("d")):
+                angles.append((b.next("d"), b.next("d"), b.next("d"), b.next("d")))
+        out.update(bonds=bonds, angles=angles)
 
     # ---- control.txt
     c = Scanner(_read(os.path.join(directory, "control.txt")))

@@ -2,14 +2,15 @@
 //
 // ref_driver: a small harness of OUR OWN that is linked against the reference's own
 // serial-path translation units, compiled where they lie under /root/reference/src
-// (box.cpp, vdw.cpp, elec.cpp, cell_list.cpp, integrators.cpp, temperature.cpp - see oracle/Makefile).
+// (box.cpp, vdw.cpp, elec.cpp, cell_list.cpp, integrators.cpp, temperature.cpp, bonds.cpp, angles.cpp -
+// see oracle/Makefile).
 // No reference source is copied here; this file only *calls* the reference through the
 // declarations in its headers (-I/root/reference/src).
 //
 // What it does: fills the reference's host model structs (Sim/Field/Atoms/Box/Elec/TStat,
 // dataStruct.h:40-416, temperature.h:15) from a binary "case" file, then replays the loop
 // body of the serial program (main.cpp:89-142): reset_chars -> integrator1 -> clear_force ->
-// forcefield -> integrate2 -> calc_chars, dumping x/v/f/energies at the requested steps.
+// forcefield -> exec_bondlist -> exec_anglelist -> integrate2 -> calc_chars, dumping x/v/f/energies at the requested steps.
 //
 // What is NOT the reference here (restated by us, cited): the input-file scanning and the
 // derived-parameter preparation of sys_init.cpp:1036-1187 / vdw.cpp:261-299, because
@@ -35,6 +36,8 @@
 #include "box.h"
 #include "cell_list.h"
 #include "integrators.h"
+#include "bonds.h"
+#include "angles.h"
 
 static void rd(FILE* f, void* p, size_t n)
 {
@@ -140,6 +143,74 @@ int main(int argc, char** argv)
     { int32_t* t = (int32_t*)malloc(4 * N); rd(f, t, 4 * (size_t)N); for (int i = 0; i < N; i++) { atm->types[i] = t[i]; atm->parents[i] = -1; } free(t); }
     rd(f, atm->xs, 8 * (size_t)N); rd(f, atm->ys, 8 * (size_t)N); rd(f, atm->zs, 8 * (size_t)N);
     rd(f, atm->vxs, 8 * (size_t)N); rd(f, atm->vys, 8 * (size_t)N); rd(f, atm->vzs, 8 * (size_t)N);
+
+    // ---- bonded terms (what read_bond bonds.cpp:125-364, read_angle angles.cpp:78-128, read_bondlist bonds.cpp:25-110
+    //      and read_anglelist angles.cpp:22-60 leave behind; constant 'con con' bonds only) ----
+    field->nBdata = 0; field->nAdata = 0; field->nBonds = 0; field->nAngles = 0;
+    if (version >= 3)
+    {
+        int nbt = rd_i(f);
+        field->nBdata = nbt ? nbt + 1 : 0;                       // [0] reserved as 'empty bond', sys_init.cpp:294
+        field->bdata = (Bond*)calloc(nbt + 1, sizeof(Bond));
+        for (int i = 1; i <= nbt; i++)
+        {
+            Bond* b = &field->bdata[i];
+            b->spec1 = rd_i(f); b->spec2 = rd_i(f); b->type = rd_i(f);
+            double p[5]; rd(f, p, 40);
+            b->hatom = -1; b->evol = 0; b->number = 0; b->mnEx = 0; b->mxEx = 0;   // bonds.cpp:144-148,262-266,285-287
+            const double r2s = r_scale * r_scale, r6 = r2s * r2s * r2s;
+            switch (b->type)                                     // unit handling of bonds.cpp:158-252 (all factors are 1.0)
+            {
+            case 1: b->p0 = p[0] * E_scale / r2s; b->p1 = p[1] * r_scale; break;
+            case 2: b->p0 = p[0] * E_scale; b->p1 = p[1] / r2s; b->p2 = p[2] * r_scale; b->p3 = p[3] * E_scale; break;
+            case 3: b->p0 = p[0] * E_scale; b->p1 = p[1] / r2s; b->p2 = p[2] * r_scale; b->p3 = p[3] * E_scale; b->p4 = p[4] * E_scale; break;
+            case 4: b->p0 = p[0] * E_scale; b->p1 = p[1] * r_scale; b->p2 = p[2] * E_scale * r6; break;
+            case 5: b->p0 = p[0] * E_scale; b->p1 = p[1] * r_scale; b->p2 = p[2] * E_scale * r6;
+                    b->p3 = p[3] * E_scale * r6 * r2s; b->p4 = p[4] * E_scale * r6 * r6; break;
+            default: fprintf(stderr, "ref_driver: unknown bond potential %d\n", b->type); return 3;
+            }
+        }
+        int nat = rd_i(f);
+        field->nAdata = nat ? nat + 1 : 0;                       // sys_init.cpp:414
+        field->adata = (Angle*)calloc(nat + 1, sizeof(Angle));
+        for (int i = 1; i <= nat; i++)
+        {
+            Angle* a = &field->adata[i];
+            a->central = rd_i(f); a->type = rd_i(f);
+            a->p0 = rd_d(f) * E_scale; a->p1 = rd_d(f);          // angles.cpp:113-119
+        }
+        int nb = rd_i(f);
+        field->nBonds = nb;
+        field->at1 = (int*)malloc(sizeof(int) * (nb + 1)); field->at2 = (int*)malloc(sizeof(int) * (nb + 1));
+        field->bTypes = (int*)malloc(sizeof(int) * (nb + 1));
+        for (int i = 0; i < nb; i++)
+        {
+            int at1 = rd_i(f), at2 = rd_i(f), k = rd_i(f);
+            if (k < 1 || k >= field->nBdata) { fprintf(stderr, "ref_driver: bond %d has unknown type %d\n", i, k); return 3; }
+            Bond* bt = &field->bdata[k];
+            if (bt->spec1 == atm->types[at1]) { if (bt->spec2 != atm->types[at2]) { fprintf(stderr, "ERROR [121]\n"); return 3; } }
+            else if (bt->spec1 == atm->types[at2])
+            {
+                if (bt->spec2 == atm->types[at1]) { int w = at1; at1 = at2; at2 = w; }   // bonds.cpp:62-67: turn the bond
+                else { fprintf(stderr, "ERROR [122]\n"); return 3; }
+            }
+            else { fprintf(stderr, "ERROR [123]\n"); return 3; }
+            bt->number++;
+            field->at1[i] = at1; field->at2[i] = at2; field->bTypes[i] = k;
+        }
+        int na = rd_i(f);
+        field->nAngles = na;
+        field->centrs = (int*)malloc(sizeof(int) * (na + 1)); field->lig1 = (int*)malloc(sizeof(int) * (na + 1));
+        field->lig2 = (int*)malloc(sizeof(int) * (na + 1)); field->angTypes = (int*)malloc(sizeof(int) * (na + 1));
+        for (int i = 0; i < na; i++)
+        {
+            field->centrs[i] = rd_i(f); field->lig1[i] = rd_i(f); field->lig2[i] = rd_i(f);
+            int x = rd_i(f);
+            if (!(x && x < field->nAdata)) { fprintf(stderr, "ERROR[013]\n"); return 3; }
+            field->angTypes[i] = x;
+            if (atm->types[field->centrs[i]] != field->adata[x].central) { fprintf(stderr, "ERROR[014]\n"); return 3; }
+        }
+    }
     fclose(f);
 
     // ---- box (read_box box.cpp:9-28 -> prepare_box) ----
@@ -157,7 +228,7 @@ int main(int argc, char** argv)
     // ---- sim: derived parameters (init_md, sys_init.cpp:1053-1112) ----
     sim->tSt = dt; sim->nSt = nsteps; sim->nEq = nEq; sim->freqEq = freqEq;
     sim->Ux = Ux; sim->Uy = 0; sim->Uz = 0; sim->shiftX = 0.0; sim->shiftVal = 0.0;
-    sim->ejtype = 0; sim->eJump = 0; sim->use_bnd = 0;
+    sim->ejtype = 0; sim->eJump = 0; sim->use_bnd = field->nBonds ? 1 : 0; sim->use_angl = field->nAngles ? 1 : 0;
     for (int i = 0; i < nSpec; i++) field->species[i].rMass_hdt = 0.5 * sim->tSt / field->species[i].mass;
     sim->rMax = 0.0;
     if (elec->type) sim->rMax = elec->rReal; else if (field->nVdW) sim->rMax = field->maxRvdw;
@@ -197,9 +268,10 @@ int main(int argc, char** argv)
     auto dump_now = [&](int step)
     {
         int32_t s = step; fwrite(&s, 4, 1, o);
-        double e[12] = { sim->engVdW, sim->engElec3, sim->engKin, sim->engTot, sim->engElecField, sim->Temp,
-                         box->momXn, box->momXp, box->momYn, box->momYp, box->momZn, box->momZp };
-        fwrite(e, 8, 12, o);
+        double e[14] = { sim->engVdW, sim->engElec3, sim->engKin, sim->engTot, sim->engElecField, sim->Temp,
+                         box->momXn, box->momXp, box->momYn, box->momYp, box->momZn, box->momZp,
+                         sim->engBond, sim->engAngle };
+        fwrite(e, 8, 14, o);
         wr_arr(o, atm->xs, N); wr_arr(o, atm->ys, N); wr_arr(o, atm->zs, N);
         wr_arr(o, atm->vxs, N); wr_arr(o, atm->vys, N); wr_arr(o, atm->vzs, N);
         wr_arr(o, atm->fxs, N); wr_arr(o, atm->fys, N); wr_arr(o, atm->fzs, N);
@@ -217,6 +289,8 @@ int main(int argc, char** argv)
         clear_force(atm, field->species, sim, box);
         sim->add_elec(atm, field, elec, box, sim);
         sim->forcefield(atm, field, elec, box, sim);
+        if (field->nBonds) exec_bondlist(atm, field, sim, box);          // reference code, main.cpp:101-104
+        if (field->nAngles) exec_anglelist(atm, field, sim, box);
         if (iSt > sim->nEq)
             integrate2(atm, field->species, sim, 0, tstat);
         else

@@ -2,7 +2,7 @@
 
 Run HERE (the container with /root/reference):   python tests/golden/make_golden.py
 It executes oracle/_ref/ref_driver (the reference's box.cpp / vdw.cpp / elec.cpp / cell_list.cpp /
-integrators.cpp compiled where they lie + our harness) on small seeded cases and stores inputs and
+integrators.cpp / temperature.cpp / bonds.cpp / angles.cpp compiled where they lie + our harness) on small seeded cases and stores inputs and
 outputs as data under tests/golden/.  No reference source text is stored.
 """
 import json
@@ -93,8 +93,69 @@ def survey_f2_case():
             "init_forces": 1, "T": 85.0}
 
 
+def bond_tables():
+    """Known answers of the five bond potentials + the harmonic-cosine angle from the reference binary
+    (bond_iter bonds.cpp:731-787, angle_iter angles.cpp:179-227): one dimer / one trimer, no pair potential."""
+    pots = {"harm": (1, [30.0, 1.0]), "mors": (2, [4.0, 2.0, 1.0, 0.5]), "pdn": (3, [4.0, 2.0, 1.0, 0.5, 0.002]),
+            "buck": (4, [2.0e4, 0.1, 1.513]), "e612": (5, [2.0e4, 0.1, 1.1467, 0.2, 0.05])}
+    out = {}
+    for name, (t, p) in pots.items():
+        rows = []
+        for r in (0.7, 0.85, 0.95, 1.0, 1.05, 1.2, 1.6, 2.5):
+            c = two_atom_case(r, [], species=((12.0, 0.0), (1.0, 0.0)), types=(0, 1))
+            c.update(nsteps=1, dump=[1], dt=1e-9, bond_types=[(0, 1, t, p)], bonds=np.array([[1, 0, 1]]))   # listed ligand-first: turned
+            d = oracle.run_ref(c)["dumps"][1]
+            rows.append({"r": r, "engBond": d["engBond"], "fx0": float(d["fx"][0]), "fx1": float(d["fx"][1])})
+        out[name] = {"type": t, "params": p, "rows": rows}
+    rows = []
+    for th in (60.0, 90.0, 104.5, 120.0, 150.0, 175.0):
+        t = np.deg2rad(th)
+        c = {"box": [60.0, 60.0, 60.0], "dt": 1e-9, "nsteps": 1, "species": [(12.0, 0.0), (1.0, 0.0)], "vdw": [],
+             "types": np.array([0, 1, 1], dtype=np.int32), "x": np.array([59.9, 0.95, 59.9 + 1.1 * np.cos(t)]),
+             "y": np.array([30.0, 30.0, 30.0 + 1.1 * np.sin(t)]), "z": np.array([30.0, 30.0, 30.0]),
+             "vx": np.zeros(3), "vy": np.zeros(3), "vz": np.zeros(3), "use_clist": 0, "init_forces": 1, "dump": [1],
+             "angle_types": [(0, 1, [3.0, -0.33])], "angles": np.array([[0, 1, 2, 1]])}
+        d = oracle.run_ref(c)["dumps"][1]
+        rows.append({"theta": th, "x": c["x"].tolist(), "y": c["y"].tolist(), "engAngle": d["engAngle"],
+                     "fx": d["fx"].tolist(), "fy": d["fy"].tolist(), "fz": d["fz"].tolist()})
+    out["hcos"] = {"params": [3.0, -0.33], "rows": rows}
+    with open(os.path.join(HERE, "bonds_kat.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+def save_bonded(name, case, dump, keep_full):
+    """Trajectory fixture of a molecular system; the case is regenerated by inputs.molecular_case in the tests,
+    the fixture keeps the inputs too so that a drift of the generator is caught."""
+    case = dict(case)
+    case["nsteps"] = max(dump)
+    case["dump"] = dump
+    ref = oracle.run_ref(case)
+    keys = EKEYS + ("engBond", "engAngle")
+    data = {"box": np.array(case["box"]), "dt": case["dt"], "types": np.asarray(case["types"], dtype=np.int32),
+            "species": np.array(case["species"]), "nHead": ref["nHead"], "cells": np.array(ref["cells"]), "steps": np.array(dump),
+            "bonds": np.asarray(case["bonds"], dtype=np.int32), "angles": np.asarray(case["angles"], dtype=np.int32)}
+    for k in ("x", "y", "z", "vx", "vy", "vz"):
+        data["in_" + k] = np.asarray(case[k])
+    for st in dump:
+        d = ref["dumps"][st]
+        data["e_%d" % st] = np.array([d[k] for k in keys])
+        for k in (("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz") if st in keep_full else ()):
+            data["%s_%d" % (k, st)] = d[k]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+    print(name, "N=%d" % len(case["types"]), "cells", ref["cells"], "nHead", ref["nHead"], "Ebond %.12e" % ref["dumps"][dump[-1]]["engBond"])
+
+
+def bonded_fixtures():
+    bond_tables()
+    save_bonded("M1_bonded", inputs.molecular_case((10, 10, 10)), [0, 1, 10, 40], keep_full=[1, 40])
+    save_bonded("M1_bonded_fenn", inputs.molecular_case((10, 10, 10), charges=(-0.2, 0.1), elec="fenn"), [0, 1, 40], keep_full=[40])
+
+
 if __name__ == "__main__":
     oracle.build()
+    if sys.argv[1:] == ["bonded"]:      # only the fixtures of the bonds + angles row (leaves the others untouched)
+        bonded_fixtures()
+        sys.exit(0)
     pair_tables()
     save_run("F1_lj", inputs.config("F1"), [0, 1, 10, 50], keep_full=[0, 1, 10, 50])
     save_run("F2_lj", inputs.config("F2"), [0, 1, 10, 50], keep_full=[0, 50])
@@ -109,3 +170,4 @@ if __name__ == "__main__":
     c = inputs.lj_case((5, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5, T=120.0, vel_T=80.0)
     c.update(tstat_type=1, tau=0.05, nEq=10, freqEq=5)
     save_run("F1_nose", c, [0, 1, 10, 40], keep_full=[1, 40])
+    bonded_fixtures()

@@ -56,6 +56,8 @@ def main():
         case.update(tstat_type=1, tau=0.05, nEq=10, freqEq=5)
     elif name == "fennel":
         case = inputs.lj_case((14, 6, 6), a=5.26, seed=7, charges=(0.2, -0.2), elec="fenn", vel_T=400.0)
+    elif name == "mol":      # bonded molecules straddle the slab boundaries and migrate across them
+        case = inputs.molecular_case((16, 6, 6), seed=9, charges=(-0.2, 0.1), elec="fenn", vel_T=900.0)
     elif name == "hot":
         case = inputs.lj_case((14, 5, 5), a=5.4, seed=3, rc=7.0, cell_list=7.0, vel_T=4000.0)
     else:
@@ -92,7 +94,7 @@ def main():
         errs = {k: rel_err(merged[k], rs[k]) for k in keys if np.abs(rs[k]).max() > 0}
         out = {"world": world, "n_atoms": len(case["types"]), "owned_total": int(counts.item()),
                "every_atom_owned_once": bool((cover.numpy() == 1).all()), "max_rel_err_vs_single": max(errs.values()), "errs": errs,
-               "energy_rel": {k: abs(st[k] - rst[k]) / (abs(rst[k]) + 1e-300) for k in ("engTot", "engVdW", "engKin", "engCoul", "engTemp") if abs(rst[k]) > 0},
+               "energy_rel": {k: abs(st[k] - rst[k]) / (abs(rst[k]) + 1e-300) for k in ("engTot", "engVdW", "engKin", "engCoul", "engTemp", "engBond", "engAngle") if abs(rst[k]) > 0},
                "cross": [st["negCross"], st["posCross"], rst["negCross"], rst["posCross"]],
                "mom_rel": rel_err(st["posMom"] + st["negMom"], rst["posMom"] + rst["negMom"]) if any(rst["posMom"] + rst["negMom"]) else 0.0}
         print("SLAB_RESULT " + json.dumps(out))

@@ -20,7 +20,7 @@ def declared_functions():
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(api.library_path())
     names = declared_functions()
-    assert len(names) >= 21
+    assert len(names) >= 22
     for n in names:
         assert hasattr(lib, n), "missing export: " + n
     assert sorted(api.EXPORTS) == names
@@ -31,7 +31,8 @@ def test_struct_layouts_match_header():
     # sizes computed from the C declarations (natural alignment, x86-64)
     assert ctypes.sizeof(api._Species) == 56 and ctypes.sizeof(api._Vdw) == 64
     assert ctypes.sizeof(api._Options) == 80 and ctypes.sizeof(api._State) == 104
-    assert ctypes.sizeof(api._Stats) == 216
+    assert ctypes.sizeof(api._Stats) == 232
+    assert ctypes.sizeof(api._BondType) == 56 and ctypes.sizeof(api._AngleType) == 24 and ctypes.sizeof(api._Bonded) == 88
 
 
 def test_no_cpu_fallback_without_gpu():

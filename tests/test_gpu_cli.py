@@ -53,3 +53,23 @@ def test_cli_reproduces_oracle(tmp_path):
     assert vel.shape == (4000, 5) and np.abs(vel[:, 2] - s["vx"]).max() < 2e-6
     tch = np.loadtxt(os.path.join(d, "tchars.dat"), skiprows=1)
     assert np.abs(tch[:, 1] - s["U"]).max() < 2e-6 and np.abs(tch[:, 2] - s["rad"]).max() < 2e-6
+
+
+def test_cli_bonded_columns(tmp_path):
+    """field.txt with 'bonds' / 'angles' + bonds.txt + angles.txt through the program: the engBnd / engAngle columns of
+    start_stat (cuStat.cu:311-314) against the oracle started from F = 0 as the GPU program is."""
+    case = inputs.molecular_case((8, 8, 8), seed=4, vel_T=None)
+    case["nsteps"] = 40
+    d = str(tmp_path / "mol")
+    inputs.write_input_files(case, d, stat=20)
+    exe = os.path.join(ROOT, "aztotmd_amd", "aztotmd")
+    r = subprocess.run([exe, d, "--out", d], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = [ln.split("\t") for ln in open(os.path.join(d, "stat.dat")).read().strip().splitlines()]
+    assert rows[0][7:9] == ["engBnd", "engAngle"] and rows[1][7:9] == ["engBnd, eV", "engAngle, eV"] and len(rows) == 4
+    o = oracle.Oracle(case)
+    for row in rows[2:]:
+        o.step(20)
+        st = o.stats()
+        for col, key in ((2, "engTot"), (3, "engKin"), (4, "engVdW"), (7, "engBond"), (8, "engAngle")):
+            assert abs(float(row[col]) - st[key]) <= 2e-6 + 1e-9 * abs(st[key]), (row[1], key, row[col], st[key])

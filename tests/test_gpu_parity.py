@@ -145,6 +145,74 @@ def test_golden_nose_hoover():
     assert abs(e.stats()["nose_conint"] - o.stats()["conint"]) < 1e-10 * abs(o.stats()["conint"])
 
 
+# ---------------------------------------------------------------------------------------------------
+# bonds + angles ("next" row f2)
+# ---------------------------------------------------------------------------------------------------
+BKEYS = EKEYS + ("engBond", "engAngle")
+
+
+@pytest.mark.parametrize("kw", [{}, dict(charges=(-0.2, 0.1), elec="fenn"), dict(cell_list=2.6)])
+def test_bonded_forces_match_oracle(kw):
+    """aztot_forces on a molecular liquid: pair + bond + angle forces and the two bonded energies vs the oracle."""
+    case = inputs.molecular_case((8, 8, 9), seed=3, **kw)
+    o = oracle.Oracle(case)
+    o.forces(0)
+    so, sto = o.state(), o.stats()
+    e = engine(case, cell_size=kw.get("cell_list", 0.0))
+    s0 = e.state()
+    o2 = oracle.Oracle(case)
+    o2.forces(2)                                  # the state after init: pair forces only (sys_init.cpp:1181-1184)
+    for k in FKEYS:
+        assert rel_err(s0[k], o2.state()[k]) < 1e-11, k
+    assert e.stats()["engBond"] == 0.0 and e.stats()["engAngle"] == 0.0
+    e.forces()
+    s, st = e.state(), e.stats()
+    for k in FKEYS:
+        assert rel_err(s[k], so[k]) < 1e-11, (k, rel_err(s[k], so[k]))
+    for a, b in (("engBond", "engBond"), ("engAngle", "engAngle"), ("engVdW", "engVdW"), ("engCoul", "engElec3")):
+        assert abs(st[a] - sto[b]) <= 1e-12 * abs(sto[b]) + 1e-14, (a, st[a], sto[b])
+    assert abs(np.sum(s["fx"])) < 1e-9 and abs(np.sum(s["fy"])) < 1e-9           # Newton's third law over all terms
+
+
+@pytest.mark.parametrize("name", ["M1_bonded", "M1_bonded_fenn"])
+def test_golden_bonded_trajectory(name):
+    """3000-atom molecular liquid against the reference binary's trajectory (5 bond potentials, hcos angles)."""
+    z = np.load(os.path.join(G, name + ".npz"))
+    kw = dict(charges=(-0.2, 0.1), elec="fenn") if name.endswith("fenn") else {}
+    case = inputs.molecular_case((10, 10, 10), **kw)
+    for k in ("x", "vx"):
+        assert np.array_equal(case[k], z["in_" + k])
+    e = engine(case)
+    done = 0
+    for st in z["steps"].tolist()[1:]:
+        e.step(st - done)
+        done = st
+        stt = e.stats()
+        ref = dict(zip(BKEYS, z["e_%d" % st].tolist()))
+        for a, b in (("engBond", "engBond"), ("engAngle", "engAngle"), ("engVdW", "engVdW"), ("engCoul", "engElec3"), ("engKin", "engKin"), ("engTot", "engTot")):
+            assert abs(stt[a] - ref[b]) <= 1e-10 * abs(ref[b]) + 1e-13, (st, a, stt[a], ref[b])
+        if ("x_%d" % st) in z:
+            s = e.state()
+            for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+                assert rel_err(s[k], z["%s_%d" % (k, st)]) < 1e-9, (st, k)
+
+
+def test_bonded_input_files_and_energy_conservation(tmp_path):
+    """from_dir (field.txt + bonds.txt + angles.txt) == from_case bit for bit; the NVE total energy of the molecular liquid stays put."""
+    case = inputs.molecular_case((8, 8, 8), seed=21, vel_T=None)       # control.txt carries 'init_vel zero'
+    d = str(tmp_path / "mol")
+    inputs.write_input_files(case, d)
+    a, b = api.Engine(api.Model.from_dir(d)), engine(case)
+    a.step(300); b.step(300)
+    sa, sb = a.state(), b.state()
+    for k in ("x", "vx", "fx"):
+        assert np.array_equal(sa[k], sb[k]), k
+    e1 = b.stats()["engTot"]
+    b.step(1700)
+    e2 = b.stats()["engTot"]
+    assert abs(e2 - e1) < 0.02 * abs(b.stats()["engKin"]), (e1, e2)      # bounded Verlet fluctuation (omega dt = 0.27 for the L-C stretch)
+
+
 def test_wall_crossing_counters_and_field():
     """hot gas: atoms cross the periodic walls; wall momenta, crossing counts and field energy vs the oracle."""
     case = mixed_case("lnjs+fenn+field", vel_T=3000.0)

@@ -85,6 +85,14 @@ def compare(directory):
                 ref = [p["type"], p["r2cut"], p["p0"], p["p1"], p["p2"], p["p3"], p["p4"], p["use_radii"]]
                 assert vd[a, b].tolist() == pytest.approx(ref, rel=1e-15, abs=0), (a, b)
     assert [int(t) for t in q("types")] == o["types"]
+    nb = [int(v) for v in q("n_bonded")]
+    assert nb == [len(o["bond_types"]), len(o["angle_types"]), len(o["bonds"]), len(o["angles"])]
+    for row, b in zip(q("bond_types").reshape(-1, 8), o["bond_types"]):
+        assert row.tolist() == [b["type"], b["spec1"], b["spec2"]] + b["p"]
+    for row, a in zip(q("angle_types").reshape(-1, 4), o["angle_types"]):
+        assert row.tolist() == [a["type"], a["central"], a["k"], a["cos0"]]
+    assert q("bonds").reshape(-1, 3).astype(int).tolist() == [list(b) for b in o["bonds"]]
+    assert q("angles").reshape(-1, 4).astype(int).tolist() == [list(a) for a in o["angles"]]
     for k in ("x", "y", "z"):
         assert np.array_equal(q(k), np.array(o[k]))
     return m, o
@@ -121,7 +129,54 @@ def test_neutral_species_demote_electrostatics(tmp_path):
     assert o["elec_type"] == 0 and o["rmax"] == 6.5          # elec.cpp:52-56 ; sys_init.cpp:1060-1071
 
 
-@pytest.mark.parametrize("text,code", [("spec 1\nAr Ar 39.9 0 0\nvdw 1\nAr Ar lnjs 4 0.01 3.4\nbonds 2\n", "out of scope"),
+def test_bonded_inputs_round_trip(tmp_path):
+    """field.txt 'bonds' / 'angles' / 'bond_list' / 'angle_list' + bonds.txt + angles.txt."""
+    case = inputs.molecular_case((5, 5, 5), charges=(-0.2, 0.1), elec="fenn")
+    d = str(tmp_path / "mol")
+    inputs.write_input_files(case, d)
+    m, o = compare(d)
+    assert len(o["bond_types"]) == 5 and len(o["angle_types"]) == 2 and len(o["bonds"]) == 250 and len(o["angles"]) == 125
+    assert o["bond_types"][3]["spec1"] == 1                      # the buck line is written L-C ...
+    assert all(o["types"][a1] == o["bond_types"][k - 1]["spec1"] for a1, a2, k in o["bonds"])    # ... and every bond is turned to it
+    m2 = api.Model.from_case(case)
+    for k in ("bond_types", "angle_types", "bonds", "angles", "n_bonded", "rmax", "degfree"):
+        assert np.array_equal(m.query(k), m2.query(k)), k
+    assert m.query("degfree")[0] == 3 * 375                      # sim->nBonds is never set: bonds do not reduce degFree (sys_init.cpp:600,1099)
+
+
+@pytest.mark.parametrize("field_edit,bonds_txt,code", [
+    (("\tcon\tcon\n", "\tcon\tbr 2.0 C L\n"), None, "out of scope"),          # breakable bond: use_bnd = 2
+    (("\tcon\tcon\n", "\tmut 0.5 2\tcon\n"), None, "out of scope"),
+    (("\tharm\t", "\tspring\t"), None, "ERROR[126]"),
+    (None, "1\n1 2 1\n", "ERROR [123]"),                                       # ligand-ligand pair for a C-L bond type
+    (None, "1\n0 1 9\n", "ERROR[121]"),
+    (None, "3\n0 1 1\n", "ERROR[121]"),                                        # truncated list
+])
+def test_bonded_error_reporting(tmp_path, field_edit, bonds_txt, code):
+    case = inputs.molecular_case((3, 3, 3))
+    d = str(tmp_path / "molbad")
+    inputs.write_input_files(case, d)
+    if field_edit:
+        text = open(os.path.join(d, "field.txt")).read()
+        assert field_edit[0] in text
+        open(os.path.join(d, "field.txt"), "w").write(text.replace(field_edit[0], field_edit[1], 1))
+    if bonds_txt:
+        open(os.path.join(d, "bonds.txt"), "w").write(bonds_txt)
+    with pytest.raises(api.AztotError) as ei:
+        api.Model.from_dir(d)
+    assert code in str(ei.value)
+
+
+def test_set_bonded_is_all_or_nothing():
+    case = inputs.molecular_case((3, 3, 3), rc=5.0)
+    m = api.Model.from_case(case)
+    before = m.query("bonds").copy()
+    with pytest.raises(api.AztotError):
+        m.set_bonded(case["bond_types"], case["angle_types"], np.array([[1, 2, 1]]), case["angles"])
+    assert np.array_equal(m.query("bonds"), before) and int(m.query("n_bonded")[2]) == 54
+
+
+@pytest.mark.parametrize("text,code", [("spec 1\nAr Ar 39.9 0 0\nvdw 1\nAr Ar lnjs 4 0.01 3.4\nlinkage 2\n", "out of scope"),
                                        ("vdw 1\nAr Ar lnjs 4 0.01 3.4\n", "ERROR[004]"),
                                        ("spec 1\nAr Ar 39.9 0 0\nvdw 1\nAr Xe lnjs 4 0.01 3.4\n", "ERROR[005]"),
                                        ("spec 1\nAr Ar 39.9 0 0\nvdw 1\nAr Ar morse 4 0.01 3.4\n", "ERROR[006]")])
