@@ -245,4 +245,6 @@ def config(name):
         return lj_case((63, 63, 63), seed=20240502, charges=(0.2, -0.2), elec="fenn")
     if name == "C4":      # 1 000 188 atoms, pure LJ
         return lj_case((63, 63, 63), seed=20240502)
+    if name == "M4":      # 1 029 000 atoms: 343 000 bent triatomics (bonds + angles), LJ + Fennell  ("next" row f2)
+        return molecular_case((70, 70, 70), seed=20240503, charges=(-0.2, 0.1), elec="fenn", quantize=False)
     raise KeyError(name)

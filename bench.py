@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="C4", help="C4 (1 000 188 Ar LJ, default), C3 (+Fennell Coulomb), C2 (40 000 Ar LJ)")
+    ap.add_argument("--workload", default="C4", help="C4 (1 000 188 Ar LJ, default), C3 (+Fennell Coulomb), C2 (40 000 Ar LJ), M4 (1 029 000 atoms in bonded triatomics)")
     ap.add_argument("--pair-variant", type=int, default=0)
     ap.add_argument("--cell-size", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
