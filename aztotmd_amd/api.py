@@ -11,7 +11,7 @@ _LIB = None
 
 STAT_FIELDS = ("step", "time", "engTot", "engKin", "engVdW", "engCoul", "engElecField", "engTemp", "engPot", "temperature",
                "posMom", "negMom", "posCross", "negCross", "pressure", "pairs_dropped", "n_cells", "nose_chit", "nose_conint",
-               "engBond", "engAngle")
+               "engBond", "engAngle", "engCoulRec", "engCoulConst")
 
 
 class AztotError(RuntimeError):
@@ -33,7 +33,8 @@ class _Control(C.Structure):
     _fields_ = [("timestep", C.c_double), ("nstep", C.c_int32), ("nequil", C.c_int32), ("eqfreq", C.c_int32),
                 ("temperature", C.c_double), ("tstat_type", C.c_int32), ("tstat_tau", C.c_double), ("elec_type", C.c_int32),
                 ("r_real", C.c_double), ("alpha", C.c_double), ("init_vel", C.c_int32), ("init_vel_par", C.c_double * 3),
-                ("elecfield", C.c_double * 3), ("use_cell_list", C.c_int32), ("cell_list", C.c_double), ("stat", C.c_int32)]
+                ("elecfield", C.c_double * 3), ("use_cell_list", C.c_int32), ("cell_list", C.c_double), ("stat", C.c_int32),
+                ("ewald_k", C.c_int32 * 3)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -72,7 +73,8 @@ class _Stats(C.Structure):
                 ("engCoul", C.c_double), ("engElecField", C.c_double), ("engTemp", C.c_double), ("engPot", C.c_double),
                 ("temperature", C.c_double), ("posMom", C.c_double * 3), ("negMom", C.c_double * 3), ("posCross", C.c_int64 * 3),
                 ("negCross", C.c_int64 * 3), ("pressure", C.c_double), ("pairs_dropped", C.c_int64), ("n_cells", C.c_int64),
-                ("nose_chit", C.c_double), ("nose_conint", C.c_double), ("engBond", C.c_double), ("engAngle", C.c_double)]
+                ("nose_chit", C.c_double), ("nose_conint", C.c_double), ("engBond", C.c_double), ("engAngle", C.c_double),
+                ("engCoulRec", C.c_double), ("engCoulConst", C.c_double)]
 
 
 class _State(C.Structure):
@@ -197,6 +199,7 @@ class Model:
         c.temperature, c.tstat_type = float(case.get("T", 0.0)), int(case.get("tstat_type", 0))
         c.tstat_tau = float(case.get("tau", 0.0))
         c.elec_type, c.r_real, c.alpha = int(case.get("elec_type", 0)), float(case.get("rReal", 0.0)), float(case.get("alpha", 0.0))
+        c.ewald_k = (C.c_int32 * 3)(*[int(v) for v in case.get("ewald_k", (0, 0, 0))])
         c.init_vel = 0
         c.elecfield = (C.c_double * 3)(case.get("Ux", 0.0), case.get("Uy", 0.0), case.get("Uz", 0.0))
         c.use_cell_list = int(case.get("use_clist", 1))

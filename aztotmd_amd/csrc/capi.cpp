@@ -100,6 +100,7 @@ int aztot_model_species_name(const aztot_model* m, int i, char* buf, int cap)
 //  rmax r2max degfree tkin cell_list use_cell_list stat init_vel elecfield nthread kB m_scale fcoul
 //  species (per species: mass_amu, mass, charge, charged, frozen, rMass_hdt, radA, radB, mxEng, number)
 //  vdw (per ordered species pair a*nSpec+b: type, r2cut, p0..p4, use_radii)
+//  ewald (kx, ky, kz, mr4a2, rkcut2, engElec1, number of k-vectors)  kvecs (l, m, n, rkx, rky, rkz, akk per k-vector)
 //  n_bonded (bond types, angle types, bonds, angles)  bond_types (type, spec1, spec2, p0..p4)  angle_types (type, central, k, cos0)
 //  bonds (at1, at2, type id per bond, after the turn of read_bondlist)  angles (central, lig1, lig2, type id)
 //  types x y z vx vy vz   (per atom)    photons uvx uvy uvz (radiative thermostat tables; seed = first element of `out` on entry for photons)
@@ -149,6 +150,9 @@ int aztot_model_query(const aztot_model* h, const char* key, double* out, int ca
         else if (k == "vdw")
             for (const auto& p : m.pairpots)
             { double r[] = {(double)p.type, p.r2cut, p.p0, p.p1, p.p2, p.p3, p.p4, (double)p.use_radii}; v.insert(v.end(), r, r + 8); }
+        else if (k == "ewald") { v = {(double)m.ewald_k[0], (double)m.ewald_k[1], (double)m.ewald_k[2], m.mr4a2, m.rkcut2, m.engElec1, (double)m.kvecs.size()}; }
+        else if (k == "kvecs")
+            for (const auto& q : m.kvecs) { double r[] = {(double)q.l, (double)q.m, (double)q.n, q.rkx, q.rky, q.rkz, q.akk}; v.insert(v.end(), r, r + 7); }
         else if (k == "n_bonded") v = {(double)m.bondTypes.size(), (double)m.angleTypes.size(), (double)m.bondA.size(), (double)m.angC.size()};
         else if (k == "bond_types")
             for (const auto& b : m.bondTypes)

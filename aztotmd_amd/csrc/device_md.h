@@ -52,6 +52,22 @@ struct BondedTables
     int32_t* idxOfId;                // [nAtGlobal]: index in the sorted arrays, verified against A.id on use
 };
 
+// reciprocal-space Ewald sum ("next" row f4): k-vector table in the order ewald_rec visits it (elec.cpp:229-330)
+enum { EWK_NEW_L = 1, EWK_NEW_LM = 2 };
+struct EwaldK
+{
+    int32_t l, m, n, flags;          // flags: first k-vector with this l / with this (l, m)
+    double rkx, rky, rkz, akk;       // rk[] and exprk2[] of cuInit.cu:1017-1046
+};
+struct EwaldTables
+{
+    const EwaldK* kv;
+    int32_t nK, kx, ky, kz, nBlocksA;
+    double* partial;                 // [nBlocksA][nK][2]: per-block partial structure factors
+    double* S;                       // [nK][2]: (sum q cos kr, sum q sin kr) over ALL atoms
+    double scale, scale2;            // elec.cpp:380-381
+};
+
 // uniform parameters of the step (kernel argument, by value)
 struct StepParams
 {
@@ -99,6 +115,7 @@ struct DevStats
     long long step;
     double engKin, engVdW, engCoul, engElecField, engTemp, engTot, engPot, temperature;
     double engBond, engAngle;     // exec_bondlist bonds.cpp:1218 / exec_anglelist angles.cpp:240
+    double engCoulRec, engCoulConst;   // Ewald sum: reciprocal (engElec2) and constant (engElec1) parts; the same on every rank
     double mom[6];                // Xn, Xp, Yn, Yp, Zn, Zp accumulated over the run (box.cpp:230-295)
     long long cross[6];
     long long dropped;

@@ -51,6 +51,8 @@ private:
     void allocate();
     void upload_initial();
     void upload_bonded();
+    void upload_ewald();
+    void launch_ewald();
     void sort_and_forces(bool integrate_first, bool withBonded = true);
     void launch_step_kernels();
     void launch_pair();
@@ -93,6 +95,8 @@ private:
     int pairBlocks_ = 0, pairBlocksUsed_ = 0;
     BondedTables bonded_{};         // all-null when the model has no bonds / angles
     bool hasBonded_ = false;
+    EwaldTables ew_{};              // reciprocal-space Ewald sum ('elec pme')
+    bool hasEwald_ = false;
 
     // statistics window for the wall-momentum pressure (main.cpp:143-163)
     double lastMom_[6] = {0, 0, 0, 0, 0, 0};

@@ -8,6 +8,7 @@
 
 #include "exchange.h"
 #include "bonded.hip.h"
+#include "ewald.hip.h"
 #include "kernels.hip.h"
 #include "pair_tile.hip.h"
 #include "slab.hip.h"
@@ -168,6 +169,7 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
     choose_cells();
     allocate();
     upload_bonded();
+    upload_ewald();
     if (nranks_ > 1 && !xch_)
     {   // options.reserved[1]: loopback measurement mode (see LoopbackExchanger)
         ownedXch_.reset(new LoopbackExchanger((P_.ncxLocal - 2 * P_.hw[0]) * P_.csz[0], P_.L[0], lay_.mig_offset(), lay_.halo_offset(),
@@ -311,6 +313,53 @@ void Engine::upload_bonded()
     bonded_.idxOfId = (int32_t*)up(none.data(), sizeof(int32_t) * (size_t)N);
 }
 
+// k-vector table of the Ewald sum + work buffers.  The table is the host model's (finish_model, same loop as ewald_rec).
+void Engine::upload_ewald()
+{
+    const Model& m = model_;
+    hasEwald_ = m.elec_type == AZTOT_ELEC_EWALD && !m.kvecs.empty();
+    if (!hasEwald_) return;
+    std::vector<EwaldK> kv(m.kvecs.size());
+    for (size_t k = 0; k < kv.size(); k++)
+    {
+        const KVec& a = m.kvecs[k];
+        int flags = 0;
+        if (k == 0 || m.kvecs[k - 1].l != a.l) flags |= EWK_NEW_L | EWK_NEW_LM;
+        else if (m.kvecs[k - 1].m != a.m) flags |= EWK_NEW_LM;
+        kv[k] = EwaldK{a.l, a.m, a.n, flags, a.rkx, a.rky, a.rkz, a.akk};
+    }
+    auto alloc = [&](size_t bytes) { void* p = nullptr; HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16))); allocs_.push_back(p); return p; };
+    EwaldK* dkv = (EwaldK*)alloc(sizeof(EwaldK) * kv.size());
+    HIP_CHECK(hipMemcpy(dkv, kv.data(), sizeof(EwaldK) * kv.size(), hipMemcpyHostToDevice));
+    ew_.kv = dkv;
+    ew_.nK = (int)kv.size(); ew_.kx = m.ewald_k[0]; ew_.ky = m.ewald_k[1]; ew_.kz = m.ewald_k[2];
+    ew_.nBlocksA = std::max(1, std::min(1024, div_up(capacity_, kEwTile)));
+    ew_.partial = (double*)alloc(sizeof(double) * 2 * (size_t)ew_.nK * ew_.nBlocksA);
+    ew_.S = (double*)alloc(sizeof(double) * 2 * (size_t)ew_.nK);
+    HIP_CHECK(hipMemset(ew_.S, 0, sizeof(double) * 2 * (size_t)ew_.nK));
+    ew_.scale = m.el_scale; ew_.scale2 = m.el_scale2;
+    DevStats s;
+    HIP_CHECK(hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost));
+    s.engCoulConst = m.engElec1;
+    HIP_CHECK(hipMemcpy(dStats_, &s, sizeof(DevStats), hipMemcpyHostToDevice));
+}
+
+// sim->add_elec = ewald_rec (main.cpp:99 ; GPU path main.cu:330-335): structure factors of the owned atoms, their sum over the
+// ranks, then energy and per-atom forces (added to what the pair kernel wrote)
+void Engine::launch_ewald()
+{
+    const size_t lds = sizeof(double) * 2 * (size_t)kEwTile * (ew_.kx + ew_.ky + ew_.kz);
+    timed("ewald_sfac", [&] {
+        hipLaunchKernelGGL(k_ewald_sfac, dim3(ew_.nBlocksA), dim3(256), lds, stream_, P_, S_, cur(), dCounts_, ew_);
+        hipLaunchKernelGGL(k_ewald_reduce, dim3(div_up(ew_.nK, 256)), dim3(256), 0, stream_, ew_);
+    });
+    if (nranks_ > 1) timed("ewald_allreduce", [&] { xch_->allreduce_device(ew_.S, 2 * ew_.nK, stream_); });
+    timed("ewald_force", [&] {
+        hipLaunchKernelGGL(k_ewald_energy, dim3(1), dim3(256), 0, stream_, ew_, dStats_);
+        hipLaunchKernelGGL(k_ewald_force, dim3(div_up(capacity_, kEwTile)), dim3(kEwTile), lds, stream_, P_, S_, cur(), dCounts_, ew_);
+    });
+}
+
 void Engine::upload_initial()
 {
     const Model& m = model_;
@@ -426,6 +475,7 @@ void Engine::sort_and_forces(bool integrate_first, bool withBonded)
     });
     cur_ ^= 1;
     launch_pair();
+    if (hasEwald_) launch_ewald();
     if (hasBonded_ && withBonded)      // exec_bondlist + exec_anglelist, main.cpp:101-104 (GPU path: main.cu:307-312,353-363)
         timed("bonded", [&] {
             hipLaunchKernelGGL(k_bonded, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, cur(), dCounts_, bonded_, dPartials_, maxBlocks_);
@@ -555,7 +605,9 @@ void Engine::get_stats(aztot_stats& out)
     out.engKin = v[0]; out.engVdW = v[1]; out.engCoul = v[2]; out.engElecField = v[3]; out.engTemp = v[4];
     out.engPot = out.engCoul + out.engVdW;
     out.engBond = v[18]; out.engAngle = v[19];
-    out.engTot = out.engElecField + out.engVdW + out.engCoul + out.engKin + out.engBond + out.engAngle;   // calc_chars integrators.cpp:71
+    out.engCoulRec = s.engCoulRec; out.engCoulConst = s.engCoulConst;      // global quantities: identical on every rank
+    out.engTot = out.engElecField + out.engVdW + (out.engCoulConst + out.engCoulRec + out.engCoul) + out.engKin + out.engBond +
+                 out.engAngle;                                             // calc_chars integrators.cpp:70-71
     out.temperature = 2.0 * out.engKin * model_.revDegFree * (1.0 / units::kB);     // integrators.cpp:67
     out.negMom[0] = v[5]; out.posMom[0] = v[6]; out.negMom[1] = v[7]; out.posMom[1] = v[8]; out.negMom[2] = v[9]; out.posMom[2] = v[10];
     out.negCross[0] = (int64_t)v[11]; out.posCross[0] = (int64_t)v[12]; out.negCross[1] = (int64_t)v[13];

@@ -39,6 +39,16 @@ void CallbackExchanger::allreduce_sum(double* host, int n, hipStream_t)
     if (ar_(ctx_, host, n) != 0) throw std::runtime_error("slab allreduce callback failed");
 }
 
+void CallbackExchanger::allreduce_device(double* dev, int n, hipStream_t stream)
+{
+    std::vector<double> h((size_t)n);
+    HIP_CHECK(hipMemcpyAsync(h.data(), dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (ar_(ctx_, h.data(), n) != 0) throw std::runtime_error("slab allreduce callback failed");
+    HIP_CHECK(hipMemcpyAsync(dev, h.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
 // ---------------------------------------------------------------------------------------------------
 // loopback transport (measurement aid)
 // ---------------------------------------------------------------------------------------------------
@@ -158,6 +168,11 @@ void RcclExchanger::allreduce_sum(double* host, int n, hipStream_t stream)
     check_nccl(rccl().AllReduce(dScratch_, dScratch_, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)comm_, stream), "ncclAllReduce");
     HIP_CHECK(hipMemcpyAsync(host, dScratch_, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void RcclExchanger::allreduce_device(double* dev, int n, hipStream_t stream)
+{
+    check_nccl(rccl().AllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)comm_, stream), "ncclAllReduce");
 }
 
 }  // namespace aztot

@@ -24,6 +24,9 @@ public:
                           size_t bytes, hipStream_t stream) = 0;
     // element-wise sum over ranks of n doubles held on the HOST (statistics; not on the per-step path)
     virtual void allreduce_sum(double* host, int n, hipStream_t stream) = 0;
+    // element-wise sum over ranks of n doubles held on the DEVICE, ordered on `stream` (Ewald structure factors: a real
+    // exchange step of the path, once per force evaluation)
+    virtual void allreduce_device(double* dev, int n, hipStream_t stream) = 0;
     virtual bool device_side() const = 0;
 };
 
@@ -34,6 +37,7 @@ public:
     void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
                   hipStream_t stream) override;
     void allreduce_sum(double* host, int n, hipStream_t stream) override;
+    void allreduce_device(double* dev, int n, hipStream_t stream) override;
     bool device_side() const override { return false; }
 
 private:
@@ -54,6 +58,7 @@ public:
     void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
                   hipStream_t stream) override;
     void allreduce_sum(double*, int, hipStream_t) override {}
+    void allreduce_device(double*, int, hipStream_t) override {}
     bool device_side() const override { return true; }
 
 private:
@@ -69,6 +74,7 @@ public:
     void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
                   hipStream_t stream) override;
     void allreduce_sum(double* host, int n, hipStream_t stream) override;
+    void allreduce_device(double* dev, int n, hipStream_t stream) override;
     bool device_side() const override { return true; }
     static int id_bytes();
     static void make_id(void* out);

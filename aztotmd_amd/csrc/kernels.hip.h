@@ -766,7 +766,7 @@ __global__ void k_finalize(StepParams P, DevStats* st, const double* __restrict_
     st->engBond = sums[PS_EBOND];
     st->engAngle = sums[PS_EANGLE];
     st->engPot = st->engCoul + st->engVdW;
-    st->engTot = st->engElecField + st->engVdW + st->engCoul + st->engKin + st->engBond + st->engAngle;
+    st->engTot = st->engElecField + st->engVdW + (st->engCoulConst + st->engCoulRec + st->engCoul) + st->engKin + st->engBond + st->engAngle;
 }
 
 }  // namespace aztot

@@ -81,7 +81,7 @@ int main(int argc, char** argv)
         if (aztot_step(md, n) != AZTOT_OK) die("step");
         done += n;
         if (aztot_get_stats(md, &st) != AZTOT_OK) die("stats");
-        std::fprintf(sf, "%f\t%d\t%f\t%f\t%f\t%f\t%f", st.time, (int)st.step, st.engTot, st.engKin, st.engVdW, st.engCoul, 0.0);
+        std::fprintf(sf, "%f\t%d\t%f\t%f\t%f\t%f\t%f", st.time, (int)st.step, st.engTot, st.engKin, st.engVdW, st.engCoul, st.engCoulRec);
         if (radi) std::fprintf(sf, "\t%f", st.engTemp);
         if (hasB) std::fprintf(sf, "\t%f", st.engBond);
         if (hasA) std::fprintf(sf, "\t%f", st.engAngle);

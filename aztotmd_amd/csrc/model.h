@@ -26,6 +26,7 @@ constexpr double pressure_factor = 1.58e6;                 // main.cpp:147 / mai
 
 constexpr int kMaxSpecies = 15;                            // defines.h:14 MX_SPEC
 constexpr int kNumUnitVectors = 3072;                      // cuTemp.h:4 nUvect
+constexpr int kEwaldKMax = 16;                             // k-vectors per axis the Ewald kernels size their LDS tables for (reference: NKVEC_MX)
 
 struct Species                                             // Spec, dataStruct.h:244-291
 {
@@ -61,6 +62,13 @@ struct AngleType                                           // Angle, dataStruct.
     int type = 0;           // 1 hcos
     int central = 0;
     double k = 0, cos0 = 0;
+};
+
+struct KVec                                                // one k-vector of the Ewald sum: rk[] / exprk2[] of cuInit.cu:1017-1046
+{
+    int l, m, n;
+    double rkx, rky, rkz;
+    double akk;             // exp(-rk^2 / 4 alpha^2) / rk^2  (elec.cpp:310)
 };
 
 struct Model
@@ -99,6 +107,10 @@ struct Model
     int elec_type = AZTOT_ELEC_NONE;
     double rReal = 0, r2Real = 0, alpha = 0, eps = 1.0;
     double el_scale = 0, el_scale2 = 0, daipi2 = 0;
+    int ewald_k[3] = {0, 0, 0};        // 'elec pme rReal alpha kx ky kz': exclusive upper bounds of |k| per axis (elec.cpp:36)
+    double mr4a2 = 0, rkcut2 = 0;      // prepare_elec elec.cpp:382-394
+    double engElec1 = 0;               // constant part of the Ewald sum (ewald_const elec.cpp:144-164)
+    std::vector<KVec> kvecs;
     // TStat (temperature.h:15)
     int tstat_type = AZTOT_TSTAT_NONE;
     double Temp = 0, tau = 0, tKin = 0;

@@ -322,9 +322,9 @@ void read_sim(const std::string& dir, Model& m)
     }
     else if (std::strcmp(s, "pme") == 0)
     {
-        int kx, ky, kz;
         m.elec_type = AZTOT_ELEC_EWALD;
-        if (std::fscanf(f, " %lf %lf %d %d %d", &m.rReal, &m.alpha, &kx, &ky, &kz) != 5) fail("ERROR[404] malformed 'elec pme'");
+        if (std::fscanf(f, " %lf %lf %d %d %d", &m.rReal, &m.alpha, &m.ewald_k[0], &m.ewald_k[1], &m.ewald_k[2]) != 5)
+            fail("ERROR[404] malformed 'elec pme'");
     }
     else if (std::strcmp(s, "fenn") == 0)
     {
@@ -565,9 +565,63 @@ double initial_radius(uint64_t seed, uint64_t id)
 
 void finish_model(Model& m, uint64_t seed)
 {
-    // prepare_elec: elec.cpp:371-406 (Fennell constants; k-space Ewald is out of scope)
+    // prepare_elec: elec.cpp:371-406
+    m.kvecs.clear(); m.engElec1 = 0.0;
     if (m.elec_type == AZTOT_ELEC_EWALD)
-        fail("out of scope: 'elec pme' (reciprocal-space Ewald) is not part of the accelerated hot path (short-range electrostatics only)");
+    {   // 'elec pme' is a plain Ewald sum in the reference (ewald_rec elec.cpp:167-335; GPU twin recip_ewald + ewald_force cuElec.cu:151-382)
+        const int kx = m.ewald_k[0], ky = m.ewald_k[1], kz = m.ewald_k[2];
+        if (kx < 1 || ky < 1 || kz < 1 || kx > kEwaldKMax || ky > kEwaldKMax || kz > kEwaldKMax)
+            fail("ERROR[404] 'elec pme' needs 1 <= kx, ky, kz <= " + std::to_string(kEwaldKMax) + " k-vectors per axis");
+        for (int k = 0; k < 3; k++) if (!(m.L[k] > 0)) fail("ERROR[008] box lengths must be positive");
+        if (!(m.alpha > 0)) fail("ERROR[404] 'elec pme' needs a positive alpha");
+        const double twopi = 2.0 * units::pi, sqrtpi = std::sqrt(units::pi);
+        const double ra = 1.0 / m.L[0], rb = 1.0 / m.L[1], rc = 1.0 / m.L[2], rvol = 1.0 / (m.L[0] * m.L[1] * m.L[2]);
+        m.daipi2 = 2 * m.alpha / sqrtpi;
+        m.el_scale = 2 * twopi * rvol * units::Fcoul_scale / m.eps;          // elec.cpp:380
+        m.el_scale2 = 2 * m.el_scale;
+        m.mr4a2 = -0.25 / m.alpha / m.alpha;
+        // ip1..ip3 come out of prepare_box's general cell-matrix algebra even for a rectangular box (box.cpp:92-151): 1/la, 1/lb,
+        // 1/lc up to rounding.  Followed operation by operation: boxes built from a lattice put k-vectors exactly ON the cut-off
+        // sphere, and there the last bit decides whether the reference includes them.
+        double ip1, ip2, ip3;
+        {
+            const double la = m.L[0], lb = m.L[1], lc = m.L[2];
+            const double axb3 = la * lb, bxc1 = lb * lc, cxa2 = la * lc;
+            const double vol = la * lb * lc, det = la * bxc1, rdet = 1.0 / det, rv = 1.0 / vol;
+            const double iax = rdet * bxc1, iby = rdet * cxa2, icz = rdet * axb3;
+            const double iaxb3 = iax * iby, ibxc1 = iby * icz, icxa2 = iax * icz;
+            ip1 = rv / std::sqrt(ibxc1 * ibxc1); ip2 = rv / std::sqrt(icxa2 * icxa2); ip3 = rv / std::sqrt(iaxb3 * iaxb3);
+        }
+        double rkcut = kx * ip1;
+        if (rkcut > ky * ip2) rkcut = ky * ip2;
+        if (rkcut > kz * ip3) rkcut = kz * ip3;
+        rkcut *= twopi * 1.05;
+        m.rkcut2 = rkcut * rkcut;
+        // the k-vector list in the order ewald_rec visits it (half space: l >= 0; m >= 0 when l == 0; n >= 1 when l == m == 0);
+        // same table the GPU reference builds on the host, cuInit.cu:1017-1046
+        int mmin = 0, nmin = 1;
+        for (int l = 0; l < kx; l++)
+        {
+            const double rkx = l * twopi * ra;
+            for (int mm = mmin; mm < ky; mm++)
+            {
+                const double rky = mm * twopi * rb;
+                for (int n = nmin; n < kz; n++)
+                {
+                    const double rkz = n * twopi * rc;
+                    const double rk2 = rkx * rkx + rky * rky + rkz * rkz;
+                    if (rk2 < m.rkcut2) m.kvecs.push_back(KVec{l, mm, n, rkx, rky, rkz, std::exp(rk2 * m.mr4a2) / rk2});
+                }
+                nmin = 1 - kz;
+            }
+            mmin = 1 - ky;
+        }
+        double sq = 0.0, eng = 0.0;                                            // ewald_const: elec.cpp:144-164
+        for (int i = 0; i < m.nAt; i++) { const double q = m.species[m.types[i]].charge; sq += q; eng += q * q; }
+        eng *= (-1.0) * m.alpha / sqrtpi;
+        const double q = -0.5 * units::pi * (sq * sq / m.alpha / m.alpha) * rvol;
+        m.engElec1 = units::Fcoul_scale * (eng + q) / m.eps;
+    }
     if (m.tstat_type == AZTOT_TSTAT_NOSE && !(m.tau > 0)) fail("ERROR[405] 'nose' needs a positive relaxation time");
     if (m.elec_type == AZTOT_ELEC_FENNEL)
     {
@@ -701,6 +755,7 @@ void model_from_system(const aztot_system& sys, Model& m)
     m.nEq = c.nequil; m.freqEq = c.nequil ? c.eqfreq : 0;
     m.Temp = c.temperature; m.tstat_type = c.tstat_type; m.tau = c.tstat_tau;
     m.elec_type = c.elec_type; m.rReal = c.r_real; m.alpha = c.alpha;
+    for (int k = 0; k < 3; k++) m.ewald_k[k] = c.ewald_k[k];
     if (m.elec_type == AZTOT_ELEC_NONE) m.rReal = 0.0;
     if (!m.charged_spec && m.elec_type) m.elec_type = AZTOT_ELEC_NONE;
     m.r2Real = m.rReal * m.rReal;

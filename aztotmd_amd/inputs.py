@@ -214,6 +214,8 @@ def write_input_files(case, directory, stat=200):
             f.write("elec\tnone\n")
         elif et == "dir":
             f.write("elec\tdir\t%r\n" % case["rReal"])
+        elif et == "pme":
+            f.write("elec\tpme\t%r\t%r\t%d\t%d\t%d\n" % ((case["rReal"], case["alpha"]) + tuple(int(v) for v in case["ewald_k"])))
         else:
             f.write("elec\t%s\t%r\t%r\n" % (et, case["rReal"], case["alpha"]))
         f.write("rdf\t8.0\t0.02\t1000000\t1000000\tnucl\n")

@@ -73,6 +73,7 @@ typedef struct
     int32_t use_cell_list;       /* 'cell_list' present */
     double cell_list;            /* desired cell edge */
     int32_t stat;                /* statistics period */
+    int32_t ewald_k[3];          /* 'elec pme rReal alpha kx ky kz' (read_elec elec.cpp:33-38): k-vectors per axis, 1..16 */
 } aztot_control;
 
 /* array form of atoms.xyz + field.txt + control.txt (used by tests / bench; same state as aztot_init_md) */
@@ -146,6 +147,8 @@ typedef struct
     int64_t n_cells;
     double nose_chit, nose_conint;  /* Nose-Hoover friction and conserved-quantity integral (temperature.h:24-25) */
     double engBond, engAngle;    /* exec_bondlist bonds.cpp:1218, exec_anglelist angles.cpp:240; both are part of engTot */
+    double engCoulRec, engCoulConst; /* Ewald sum: reciprocal part (engElec2, elec.cpp:333 ; cudaMD::engCoul2) and constant part
+                                        (engElec1, ewald_const elec.cpp:144 ; engCoul3); engCoul above is the real-space part */
 } aztot_stats;
 
 /* host copy of the per-atom state, fp64 SoA, in ORIGINAL atom order (id order); any pointer may be NULL */

@@ -68,6 +68,8 @@ typedef struct
     double maxRvdw;
     /* elec: dataStruct.h:349-366 */
     int elec_type; double rReal, r2Real, alpha, el_scale, el_scale2, daipi2;
+    int kx, ky, kz; double mr4a2, rkcut2, engElec1, engElec2;      /* Ewald sum: elec.cpp:371-397 */
+    double *ew;                                                      /* per-atom work arrays of init_ewald, elec.cpp:69-129 */
     double rMax, r2Max;
     double Ux, Uy, Uz;
     /* thermostat + control */
@@ -147,6 +149,7 @@ void orc_free(orc_sys *s)
     free(s->charged); free(s->frozen); free(s->vdw);
     free(s->clist); free(s->chead); free(s->neig);
     free(s->photons); free(s->uvx); free(s->uvy); free(s->uvz);
+    free(s->ew);
     free(s->bdata); free(s->adata); free(s->at1); free(s->at2); free(s->bTypes);
     free(s->centrs); free(s->lig1); free(s->lig2); free(s->angTypes);
     free(s);
@@ -194,6 +197,8 @@ void orc_set_elec(orc_sys *s, int type, double rReal, double alpha)
 }
 
 void orc_set_nose(orc_sys *s, double tau) { s->tau = tau; }
+/* 'elec pme rReal alpha kx ky kz' (read_elec elec.cpp:33-38): numbers of k-vectors per axis, exclusive upper bounds */
+void orc_set_ewald(orc_sys *s, int kx, int ky, int kz) { s->kx = kx; s->ky = ky; s->kz = kz; }
 
 void orc_set_control(orc_sys *s, double dt, double T, int tstat_type, int nEq, int freqEq, int use_clist,
                      double Ux, double Uy, double Uz, uint64_t seed)
@@ -315,6 +320,39 @@ int orc_prepare(orc_sys *s)
         s->daipi2 = 2 * s->alpha / sqrtpi;
         s->el_scale = erfc(aRc) / s->rReal;
         s->el_scale2 = erfc(aRc) / s->r2Real + s->daipi2 * exp(-aRc * aRc) / s->rReal;
+    }
+    s->engElec1 = 0.0; s->engElec2 = 0.0;
+    if (s->elec_type == ELEC_EWALD)
+    {   /* prepare_elec: elec.cpp:377-397 (eps = 1) ; ewald_const :144-164 */
+        const double twopi = 2.0 * ORC_PI, sqrtpi = sqrt(ORC_PI), rvol = 1.0 / (s->la * s->lb * s->lc);
+        s->daipi2 = 2 * s->alpha / sqrtpi;
+        s->el_scale = 2 * twopi * rvol * c_Fcoul() / 1.0;
+        s->el_scale2 = 2 * s->el_scale;
+        s->mr4a2 = -0.25 / s->alpha / s->alpha;
+        /* ip1..ip3 ("perpendicular widths" for the k cut-off) come out of prepare_box's general cell-matrix algebra even for a
+           rectangular box (box.cpp:92-151): equal to 1/la, 1/lb, 1/lc up to rounding - restated literally because lattice-built
+           boxes put k-vectors EXACTLY on the cut-off sphere, where the last bit decides membership */
+        double ip1, ip2, ip3;
+        {
+            const double la = s->la, lb = s->lb, lc = s->lc;
+            const double axb3 = la * lb, bxc1 = lb * lc, cxa2 = la * lc;                 /* box.cpp:92-104 */
+            const double vol = la * lb * lc, det = la * bxc1, rdet = 1.0 / det, rv = 1.0 / vol;   /* :110-119 */
+            const double iax = rdet * bxc1, iby = rdet * cxa2, icz = rdet * axb3;          /* :123-133 */
+            const double iaxb3 = iax * iby, ibxc1 = iby * icz, icxa2 = iax * icz;          /* :136-146 */
+            ip1 = rv / sqrt(ibxc1 * ibxc1); ip2 = rv / sqrt(icxa2 * icxa2); ip3 = rv / sqrt(iaxb3 * iaxb3);   /* :149-151 */
+        }
+        double rkcut = s->kx * ip1;
+        if (rkcut > s->ky * ip2) rkcut = s->ky * ip2;
+        if (rkcut > s->kz * ip3) rkcut = s->kz * ip3;
+        rkcut *= twopi * 1.05;
+        s->rkcut2 = rkcut * rkcut;
+        double sq = 0.0, eng = 0.0;
+        for (int i = 0; i < s->N; i++) { double q = s->charge[s->types[i]]; sq += q; eng += q * q; }
+        eng *= (-1.0) * s->alpha / sqrtpi;
+        double q = -0.5 * ORC_PI * (sq * sq / s->alpha / s->alpha) * rvol;
+        s->engElec1 = c_Fcoul() * (eng + q) / 1.0;
+        free(s->ew);
+        s->ew = (double *)malloc(sizeof(double) * (size_t)s->N * (size_t)(2 * (2 + s->ky + s->kz) + 4));
     }
     for (int i = 0; i < s->nSpec; i++) s->rMass_hdt[i] = 0.5 * s->dt / s->mass[i];    /* :1056-1057 */
     s->rMax = 0.0;
@@ -621,7 +659,7 @@ static void integrate2(orc_sys *s, int tScale)
 static void calc_chars(orc_sys *s)
 {   /* calc_chars: integrators.cpp:63-73 (engElec1/2 and engOwn are 0 on this path) */
     s->TempNow = 2.0 * s->engKin * (double)(1.0 / s->degFree) * (1.0 / c_kB());
-    s->engTot = s->engElecField + s->engVdW + s->engElec3 + s->engKin + s->engBond + s->engAngle;
+    s->engTot = s->engElecField + s->engVdW + (s->engElec1 + s->engElec2 + s->engElec3) + s->engKin + s->engBond + s->engAngle;
 }
 
 /* ---------------------------------------------------------------- radiative thermostat (cuTemp.cu, fp64 restatement) */
@@ -696,6 +734,113 @@ static void tstat_radi(orc_sys *s, uint64_t step)
         }
         s->engTemp += s->U[i];
     }
+}
+
+/* ewald_rec: elec.cpp:167-335.  Reciprocal part of the Ewald sum over l in [0,kx), m in (-ky,ky), n in (-kz,kz) (half space),
+   rk2 < rkcut2.  Adds to the forces, leaves engElec2.  Array names follow the reference; storage is one block. */
+static void ewald_rec(orc_sys *s)
+{
+    const int Nat = s->N, kx = s->kx, ky = s->ky, kz = s->kz;
+    const double twopi = 2.0 * ORC_PI;
+    double *elc = s->ew, *els = elc + 2 * (size_t)Nat;                     /* [i*2 + {0,1}] */
+    double *emc = els + 2 * (size_t)Nat, *ems = emc + (size_t)ky * Nat;    /* [i*ky + m] */
+    double *enc = ems + (size_t)ky * Nat, *ens = enc + (size_t)kz * Nat;   /* [i*kz + n] */
+    double *lmc = ens + (size_t)kz * Nat, *lms = lmc + Nat, *ckc = lms + Nat, *cks = ckc + Nat;
+    int mmin = 0, nmin = 1;
+    double eng = 0.0;
+    for (int i = 0; i < Nat; i++)
+    {
+        elc[i * 2] = 1.0; els[i * 2] = 0.0;
+        emc[(size_t)i * ky] = 1.0; ems[(size_t)i * ky] = 0.0;              /* init_ewald: elec.cpp:105-107,121-123 */
+        enc[(size_t)i * kz] = 1.0; ens[(size_t)i * kz] = 0.0;
+        double a;
+        a = twopi * s->x[i] * s->ra; els[i * 2 + 1] = sin(a); elc[i * 2 + 1] = cos(a);                           /* sincos, :205-207 */
+        a = twopi * s->y[i] * s->rb; if (ky > 1) { ems[(size_t)i * ky + 1] = sin(a); emc[(size_t)i * ky + 1] = cos(a); }
+        a = twopi * s->z[i] * s->rc_; if (kz > 1) { ens[(size_t)i * kz + 1] = sin(a); enc[(size_t)i * kz + 1] = cos(a); }
+    }
+    for (int l = 2; l < ky; l++)
+        for (int i = 0; i < Nat; i++)
+        {
+            double *c = emc + (size_t)i * ky, *sn = ems + (size_t)i * ky;
+            c[l] = c[l - 1] * c[1] - sn[l - 1] * sn[1];
+            sn[l] = sn[l - 1] * c[1] + c[l - 1] * sn[1];
+        }
+    for (int l = 2; l < kz; l++)
+        for (int i = 0; i < Nat; i++)
+        {
+            double *c = enc + (size_t)i * kz, *sn = ens + (size_t)i * kz;
+            c[l] = c[l - 1] * c[1] - sn[l - 1] * sn[1];
+            sn[l] = sn[l - 1] * c[1] + c[l - 1] * sn[1];
+        }
+    for (int l = 0; l < kx; l++)
+    {
+        const double rkx = l * twopi * s->ra;
+        if (l == 1)
+            for (int i = 0; i < Nat; i++) { elc[i * 2] = elc[i * 2 + 1]; els[i * 2] = els[i * 2 + 1]; }
+        else if (l > 1)
+            for (int i = 0; i < Nat; i++)
+            {
+                double x = elc[i * 2];
+                elc[i * 2] = x * elc[i * 2 + 1] - els[i * 2] * els[i * 2 + 1];
+                els[i * 2] = els[i * 2] * elc[i * 2 + 1] + x * els[i * 2 + 1];
+            }
+        for (int m = mmin; m < ky; m++)
+        {
+            const double rky = m * twopi * s->rb;
+            if (m >= 0)
+                for (int i = 0; i < Nat; i++)
+                {
+                    const double ec = emc[(size_t)i * ky + m], es = ems[(size_t)i * ky + m];
+                    lmc[i] = elc[i * 2] * ec - els[i * 2] * es;
+                    lms[i] = els[i * 2] * ec + es * elc[i * 2];
+                }
+            else
+                for (int i = 0; i < Nat; i++)
+                {
+                    const double ec = emc[(size_t)i * ky - m], es = ems[(size_t)i * ky - m];
+                    lmc[i] = elc[i * 2] * ec + els[i * 2] * es;
+                    lms[i] = els[i * 2] * ec - es * elc[i * 2];
+                }
+            for (int n = nmin; n < kz; n++)
+            {
+                const double rkz = n * twopi * s->rc_;
+                const double rk2 = rkx * rkx + rky * rky + rkz * rkz;
+                if (rk2 < s->rkcut2)
+                {
+                    double sumC = 0, sumS = 0;
+                    if (n >= 0)
+                        for (int i = 0; i < Nat; i++)
+                        {
+                            const double ch = s->charge[s->types[i]];
+                            const double ec = enc[(size_t)i * kz + n], es = ens[(size_t)i * kz + n];
+                            ckc[i] = ch * (lmc[i] * ec - lms[i] * es);
+                            cks[i] = ch * (lms[i] * ec + lmc[i] * es);
+                            sumC += ckc[i]; sumS += cks[i];
+                        }
+                    else
+                        for (int i = 0; i < Nat; i++)
+                        {
+                            const double ch = s->charge[s->types[i]];
+                            const double ec = enc[(size_t)i * kz - n], es = ens[(size_t)i * kz - n];
+                            ckc[i] = ch * (lmc[i] * ec + lms[i] * es);
+                            cks[i] = ch * (lms[i] * ec - lmc[i] * es);
+                            sumC += ckc[i]; sumS += cks[i];
+                        }
+                    const double akk = exp(rk2 * s->mr4a2) / rk2;
+                    eng += akk * (sumC * sumC + sumS * sumS);
+                    for (int i = 0; i < Nat; i++)
+                    {
+                        double x = akk * (cks[i] * sumC - ckc[i] * sumS);
+                        x *= s->el_scale2;
+                        s->fx[i] += rkx * x; s->fy[i] += rky * x; s->fz[i] += rkz * x;
+                    }
+                }
+            }
+            nmin = 1 - kz;
+        }
+        mmin = 1 - ky;
+    }
+    s->engElec2 = s->el_scale * eng;
 }
 
 /* ---------------------------------------------------------------- bonds.cpp / angles.cpp (constant bonds, hcos angles) */
@@ -871,6 +1016,7 @@ void orc_forces(orc_sys *s, int mode)
 {
     reset_chars(s);
     clear_force(s);
+    if (s->elec_type == ELEC_EWALD) ewald_rec(s);                          /* add_elec: sys_init.cpp:1183 / main.cpp:99 */
     if ((mode & 1) && s->nHead) { build_clist(s); cell_list_forces(s); } else all_pairs(s);
     if (!(mode & 2))
     {
@@ -887,6 +1033,7 @@ void orc_step(orc_sys *s, int nsteps)
         reset_chars(s);
         integrate1(s);
         clear_force(s);
+        if (s->elec_type == ELEC_EWALD) ewald_rec(s);                      /* sim->add_elec, main.cpp:99 */
         if (s->nHead) cell_list_forces(s); else all_pairs(s);
         if (s->nBonds) exec_bondlist(s);                                   /* main.cpp:101-104 */
         if (s->nAngles) exec_anglelist(s);
@@ -919,13 +1066,14 @@ void orc_set_thermo(orc_sys *s, const double *U, const double *rad)
 { size_t nb = 8 * (size_t)s->N; if (U) memcpy(s->U, U, nb); if (rad) memcpy(s->rad, rad, nb); }
 const double *orc_photons(const orc_sys *s) { return s->photons; }
 
-/* out[0..19]: engVdW, engElec3, engKin, engTot, engElecField, engTemp, Temp, mom[6], nDropped, iStep, tKin, chit, conint, engBond, engAngle */
+/* out[0..21]: engVdW, engElec3, engKin, engTot, engElecField, engTemp, Temp, mom[6], nDropped, iStep, tKin, chit, conint, engBond, engAngle,
+   engElec1 (Ewald constant), engElec2 (Ewald reciprocal) */
 void orc_get_stats(const orc_sys *s, double *out)
 {
     out[0] = s->engVdW; out[1] = s->engElec3; out[2] = s->engKin; out[3] = s->engTot; out[4] = s->engElecField;
     out[5] = s->engTemp; out[6] = s->TempNow;
     for (int k = 0; k < 6; k++) out[7 + k] = s->mom[k];
     out[13] = (double)s->nDropped; out[14] = (double)s->iStep; out[15] = s->tKin;
-    out[16] = s->chit; out[17] = s->conint; out[18] = s->engBond; out[19] = s->engAngle;
+    out[16] = s->chit; out[17] = s->conint; out[18] = s->engBond; out[19] = s->engAngle; out[20] = s->engElec1; out[21] = s->engElec2;
 }
 void orc_get_cross(const orc_sys *s, long long *out) { for (int k = 0; k < 6; k++) out[k] = s->cross[k]; }

@@ -19,8 +19,9 @@ Layout (little endian):
   i32 nBondTypes x (i32 spec1, spec2, type(1 harm 2 mors 3 pdn 4 buck 5 e612), f64 p[5])
   i32 nAngleTypes x (i32 central, type(1 hcos), f64 k, cos0)
   i32 nBonds x (i32 at1, at2, type 1-based) ; i32 nAngles x (i32 central, lig1, lig2, type 1-based)
+  (version >= 4) i32 kx, ky, kz  - 'elec pme rReal alpha kx ky kz' (read_elec, elec.cpp:33-38)
 
-Output of ref_driver: i32 N, nHead, cn(packed), ndump ; per dump: i32 step, f64 e[14], 9 x f64[N].
+Output of ref_driver: i32 N, nHead, cn(packed), ndump ; per dump: i32 step, f64 e[16], 9 x f64[N].
 """
 import struct
 import numpy as np
@@ -28,7 +29,7 @@ import numpy as np
 VDW_TYPES = {"lnjs": 1, "buck": 2, "p746": 3, "bmhs": 4, "elin": 5, "einv": 6, "surk": 7}
 ELEC_TYPES = {"none": 0, "dir": 1, "pme": 2, "fenn": 3}
 ENERGY_FIELDS = ("engVdW", "engElec3", "engKin", "engTot", "engElecField", "Temp",
-                 "momXn", "momXp", "momYn", "momYp", "momZn", "momZp", "engBond", "engAngle")
+                 "momXn", "momXp", "momYn", "momYp", "momZn", "momZp", "engBond", "engAngle", "engElec1", "engElec2")
 BOND_TYPES = {"harm": 1, "mors": 2, "pdn": 3, "buck": 4, "e612": 5}
 
 
@@ -39,7 +40,7 @@ def write_case(path, case):
     dump = list(case.get("dump", [0]))
     with open(path, "wb") as f:
         f.write(b"AZTC")
-        f.write(struct.pack("<i", 3))
+        f.write(struct.pack("<i", 4))
         f.write(struct.pack("<iii", N, len(species), len(vdw)))
         f.write(struct.pack("<ddd", *case["box"]))
         f.write(struct.pack("<d", case["dt"]))
@@ -72,6 +73,7 @@ def write_case(path, case):
         f.write(np.ascontiguousarray(bonds).tobytes())
         f.write(struct.pack("<i", len(angles)))
         f.write(np.ascontiguousarray(angles).tobytes())
+        f.write(struct.pack("<iii", *[int(v) for v in case.get("ewald_k", (0, 0, 0))]))
 
 
 def read_ref_output(path):
@@ -83,7 +85,7 @@ def read_ref_output(path):
             if len(hdr) < 4:
                 break
             (step,) = struct.unpack("<i", hdr)
-            e = struct.unpack("<14d", f.read(112))
+            e = struct.unpack("<16d", f.read(128))
             d = dict(zip(ENERGY_FIELDS, e))
             for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
                 d[k] = np.frombuffer(f.read(8 * N), dtype="<f8").copy()

@@ -17,7 +17,7 @@ _LIB = None
 
 STAT_FIELDS = ("engVdW", "engElec3", "engKin", "engTot", "engElecField", "engTemp", "Temp",
                "momXn", "momXp", "momYn", "momYp", "momZn", "momZp", "nDropped", "iStep", "tKin", "chit", "conint",
-               "engBond", "engAngle")
+               "engBond", "engAngle", "engElec1", "engElec2")
 
 
 def build(force=False):
@@ -51,6 +51,7 @@ def lib():
                                       C.c_double, C.c_double, C.c_double, C.c_uint64]
         L.orc_prepare.argtypes = [C.c_void_p]
         L.orc_set_nose.argtypes = [C.c_void_p, C.c_double]
+        L.orc_set_ewald.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_center_box.argtypes = [C.c_void_p]
         L.orc_forces.argtypes = [C.c_void_p, C.c_int]
         L.orc_step.argtypes = [C.c_void_p, C.c_int]
@@ -124,6 +125,7 @@ class Oracle:
                           case.get("freqEq", 1), case.get("use_clist", 1), case.get("Ux", 0.0), case.get("Uy", 0.0),
                           case.get("Uz", 0.0), case.get("seed", 12345))
         L.orc_set_nose(self.h, case.get("tau", 0.0))
+        L.orc_set_ewald(self.h, *[int(v) for v in case.get("ewald_k", (0, 0, 0))])
         L.orc_prepare(self.h)
         self._set_bonded(case)
         if case.get("center_box", 0):
@@ -182,7 +184,7 @@ class Oracle:
         return out
 
     def stats(self):
-        s = np.empty(20)
+        s = np.empty(22)
         self.L.orc_get_stats(self.h, _dp(s))
         d = dict(zip(STAT_FIELDS, s.tolist()))
         cr = (C.c_longlong * 6)()

@@ -265,10 +265,12 @@ def parse_dir(directory, with_atoms=True):
         raise ValueError("ERROR[401]")
     elec = {"none": 0, "dir": 1, "pme": 2, "fenn": 3}[es]
     r_real = alpha = 0.0
+    ewald_k = [0, 0, 0]
     if es == "dir":
         r_real = c.next("f")
     elif es == "pme":
         r_real, alpha = c.next("f"), c.next("f")
+        ewald_k = [c.next("d"), c.next("d"), c.next("d")]
     elif es == "fenn":
         r_real, alpha = c.next("f"), c.next("f")
     if not charged_spec and elec:
@@ -290,7 +292,7 @@ def parse_dir(directory, with_atoms=True):
     stat = c.find(" stat %d ")
     out.update(dt=dt, nstep=nstep, nequil=nequil, eqfreq=eqfreq, temperature=T, tstat_type=tstat, tau=tau, elec_type=elec,
                r_real=r_real, alpha=alpha, init_vel=init_vel, init_vel_par=ivp, elecfield=E, use_cell_list=int(cl is not None),
-               cell_list=cl or 0.0, stat=stat if stat is not None else 1000)
+               cell_list=cl or 0.0, stat=stat if stat is not None else 1000, ewald_k=ewald_k)
 
     # ---- cuda.txt (optional)
     cp = os.path.join(directory, "cuda.txt")
@@ -313,6 +315,46 @@ def parse_dir(directory, with_atoms=True):
         daipi2 = 2 * alpha / math.sqrt(PI)
         out.update(daipi2=daipi2, scale=math.erfc(aRc) / r_real,
                    scale2=math.erfc(aRc) / (r_real * r_real) + daipi2 * math.exp(-aRc * aRc) / r_real)
+    elif elec == 2:
+        # prepare_elec elec.cpp:377-397 + the k-vector loop of ewald_rec elec.cpp:229-330 / cuInit.cu:1017-1046 + ewald_const :144-164
+        twopi = 2.0 * PI
+        ra, rb, rc = 1.0 / box[0], 1.0 / box[1], 1.0 / box[2]
+        rvol = 1.0 / (box[0] * box[1] * box[2])
+        scale = 2 * twopi * rvol * FCOUL / 1.0
+        # ip1..3 through prepare_box's cell-matrix algebra (box.cpp:92-151): 1/la, 1/lb, 1/lc up to rounding, which matters for
+        # k-vectors that sit exactly on the cut-off sphere
+        la, lb, lc = box
+        axb3, bxc1, cxa2 = la * lb, lb * lc, la * lc
+        rdet, rv = 1.0 / (la * bxc1), 1.0 / (la * lb * lc)
+        iax, iby, icz = rdet * bxc1, rdet * cxa2, rdet * axb3
+        ip = [rv / math.sqrt((iby * icz) * (iby * icz)), rv / math.sqrt((iax * icz) * (iax * icz)), rv / math.sqrt((iax * iby) * (iax * iby))]
+        rkcut = ewald_k[0] * ip[0]
+        if rkcut > ewald_k[1] * ip[1]:
+            rkcut = ewald_k[1] * ip[1]
+        if rkcut > ewald_k[2] * ip[2]:
+            rkcut = ewald_k[2] * ip[2]
+        rkcut *= twopi * 1.05
+        mr4a2 = -0.25 / alpha / alpha
+        kvecs = []
+        mmin, nmin = 0, 1
+        for l in range(ewald_k[0]):
+            for m in range(mmin, ewald_k[1]):
+                for n in range(nmin, ewald_k[2]):
+                    rk = (l * twopi * ra, m * twopi * rb, n * twopi * rc)
+                    rk2 = rk[0] * rk[0] + rk[1] * rk[1] + rk[2] * rk[2]
+                    if rk2 < rkcut * rkcut:
+                        kvecs.append((l, m, n) + rk + (math.exp(rk2 * mr4a2) / rk2,))
+                nmin = 1 - ewald_k[2]
+            mmin = 1 - ewald_k[1]
+        sq = eng = 0.0
+        if with_atoms:
+            for t in out["types"]:
+                q = species[t]["charge"]
+                sq += q
+                eng += q * q
+        eng *= (-1.0) * alpha / math.sqrt(PI)
+        out.update(daipi2=2 * alpha / math.sqrt(PI), scale=scale, scale2=2 * scale, kvecs=kvecs,
+                   eng_elec1=FCOUL * (eng + (-0.5 * PI * (sq * sq / alpha / alpha) * rvol)) / 1.0)
     else:
         out.update(daipi2=0.0, scale=0.0, scale2=0.0)
     return out

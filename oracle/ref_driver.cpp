@@ -39,6 +39,12 @@
 #include "bonds.h"
 #include "angles.h"
 
+// NOT the reference: ewald_rec (elec.cpp:205-207) calls the reference's own helper sincos(), which lives in utils.cpp - the one
+// translation unit that cannot be compiled here (<conio.h>).  Its body (utils.cpp:65-80) is `s = sin(arg); c = cos(arg);`
+// (the fsincos asm is commented out there); this harness restates exactly that, so the Ewald pin is "the reference's compiled
+// ewald_rec / ewald_const / coul_iter + two libm calls made from here".  No header, library or tool is faked.
+void sincos(double arg, double& s, double& c) { s = sin(arg); c = cos(arg); }
+
 static void rd(FILE* f, void* p, size_t n)
 {
     if (fread(p, 1, n, f) != n) { fprintf(stderr, "ref_driver: short read\n"); exit(2); }
@@ -211,6 +217,8 @@ int main(int argc, char** argv)
             if (atm->types[field->centrs[i]] != field->adata[x].central) { fprintf(stderr, "ERROR[014]\n"); return 3; }
         }
     }
+    int ewk[3] = {0, 0, 0};
+    if (version >= 4) { ewk[0] = rd_i(f); ewk[1] = rd_i(f); ewk[2] = rd_i(f); }
     fclose(f);
 
     // ---- box (read_box box.cpp:9-28 -> prepare_box) ----
@@ -222,8 +230,10 @@ int main(int argc, char** argv)
     if (!field->charged_spec && elec->type) elec->type = tpElecNone;   // elec.cpp:52-56
     if (elec->type == tpElecNone) { /* rReal kept as given; unused */ }
     elec->r2Real = elec->rReal * elec->rReal;
-    if (elec->type == tpElecEwald) { fprintf(stderr, "ref_driver: k-space Ewald is out of scope\n"); return 3; }
-    prepare_elec(atm, field, elec, sim, box);            // reference code (Fennel constants)
+    elec->kx = ewk[0]; elec->ky = ewk[1]; elec->kz = ewk[2];                         // read_elec elec.cpp:36
+    if (elec->type == tpElecEwald && (ewk[0] < 1 || ewk[1] < 2 || ewk[2] < 2)) { fprintf(stderr, "ref_driver: Ewald needs kx >= 1, ky, kz >= 2\n"); return 3; }
+    init_elec(elec, box, sim, atm);                      // reference code (Ewald work arrays), sys_init.cpp:1048
+    prepare_elec(atm, field, elec, sim, box);            // reference code (Fennel / Ewald constants, ewald_const)
 
     // ---- sim: derived parameters (init_md, sys_init.cpp:1053-1112) ----
     sim->tSt = dt; sim->nSt = nsteps; sim->nEq = nEq; sim->freqEq = freqEq;
@@ -253,10 +263,10 @@ int main(int argc, char** argv)
     else { sim->integrator1 = integrate1; sim->forcefield = all_pairs; }
     sim->pair = pair_inter;
     sim->pair_elec = pair_elecs[elec->type];
-    sim->add_elec = no_elec;
+    sim->add_elec = add_elecs[elec->type];                    // ewald_rec for 'pme' (reference code), elec.h:46
     reset_chars(sim);
     clear_force(atm, field->species, sim, box);
-    if (init_forces) all_pairs(atm, field, elec, box, sim);   // sys_init.cpp:1181-1184
+    if (init_forces) { sim->add_elec(atm, field, elec, box, sim); all_pairs(atm, field, elec, box, sim); }   // sys_init.cpp:1181-1184
 
     FILE* o = fopen(argv[2], "wb");
     if (!o) { perror(argv[2]); return 2; }
@@ -268,10 +278,10 @@ int main(int argc, char** argv)
     auto dump_now = [&](int step)
     {
         int32_t s = step; fwrite(&s, 4, 1, o);
-        double e[14] = { sim->engVdW, sim->engElec3, sim->engKin, sim->engTot, sim->engElecField, sim->Temp,
+        double e[16] = { sim->engVdW, sim->engElec3, sim->engKin, sim->engTot, sim->engElecField, sim->Temp,
                          box->momXn, box->momXp, box->momYn, box->momYp, box->momZn, box->momZp,
-                         sim->engBond, sim->engAngle };
-        fwrite(e, 8, 14, o);
+                         sim->engBond, sim->engAngle, sim->engElec1, sim->engElec2 };
+        fwrite(e, 8, 16, o);
         wr_arr(o, atm->xs, N); wr_arr(o, atm->ys, N); wr_arr(o, atm->zs, N);
         wr_arr(o, atm->vxs, N); wr_arr(o, atm->vys, N); wr_arr(o, atm->vzs, N);
         wr_arr(o, atm->fxs, N); wr_arr(o, atm->fys, N); wr_arr(o, atm->fzs, N);

@@ -151,8 +151,39 @@ def bonded_fixtures():
     save_bonded("M1_bonded_fenn", inputs.molecular_case((10, 10, 10), charges=(-0.2, 0.1), elec="fenn"), [0, 1, 40], keep_full=[40])
 
 
+def ewald_case():
+    """500 ions (+-0.4 e, LJ) with the full Ewald sum: 'elec pme 6.5 0.45 6 6 6'."""
+    c = inputs.lj_case((5, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5, charges=(0.4, -0.4), elec="fenn", r_real=6.5, alpha=0.45, vel_T=80.0)
+    c.update(elec_type=2, ewald_k=(6, 6, 6))
+    return c
+
+
+def ewald_fixtures():
+    """Trajectory with the reference's ewald_rec / ewald_const / coul_iter (elec.cpp) in the loop."""
+    case = ewald_case()
+    dump = [0, 1, 10, 40]
+    case.update(nsteps=40, dump=dump)
+    ref = oracle.run_ref(case)
+    keys = EKEYS + ("engBond", "engAngle", "engElec1", "engElec2")
+    data = {"box": np.array(case["box"]), "dt": case["dt"], "types": np.asarray(case["types"], dtype=np.int32),
+            "species": np.array(case["species"]), "nHead": ref["nHead"], "cells": np.array(ref["cells"]), "steps": np.array(dump)}
+    for k in ("x", "y", "z", "vx", "vy", "vz"):
+        data["in_" + k] = np.asarray(case[k])
+    for st in dump:
+        d = ref["dumps"][st]
+        data["e_%d" % st] = np.array([d[k] for k in keys])
+        for k in (("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz") if st in (0, 40) else ()):
+            data["%s_%d" % (k, st)] = d[k]
+    np.savez_compressed(os.path.join(HERE, "E1_ewald.npz"), **data)
+    d = ref["dumps"][40]
+    print("E1_ewald", "N=%d" % len(case["types"]), "Econst %.9f Erec %.9f Ereal %.9f" % (d["engElec1"], d["engElec2"], d["engElec3"]))
+
+
 if __name__ == "__main__":
     oracle.build()
+    if sys.argv[1:] == ["ewald"]:
+        ewald_fixtures()
+        sys.exit(0)
     if sys.argv[1:] == ["bonded"]:      # only the fixtures of the bonds + angles row (leaves the others untouched)
         bonded_fixtures()
         sys.exit(0)
@@ -171,3 +202,4 @@ if __name__ == "__main__":
     c.update(tstat_type=1, tau=0.05, nEq=10, freqEq=5)
     save_run("F1_nose", c, [0, 1, 10, 40], keep_full=[1, 40])
     bonded_fixtures()
+    ewald_fixtures()

@@ -58,6 +58,9 @@ def main():
         case = inputs.lj_case((14, 6, 6), a=5.26, seed=7, charges=(0.2, -0.2), elec="fenn", vel_T=400.0)
     elif name == "mol":      # bonded molecules straddle the slab boundaries and migrate across them
         case = inputs.molecular_case((16, 6, 6), seed=9, charges=(-0.2, 0.1), elec="fenn", vel_T=900.0)
+    elif name == "ewald":    # structure factors are summed over the ranks every step
+        case = inputs.lj_case((14, 5, 5), a=5.26, seed=8, rc=6.5, cell_list=6.5, charges=(0.4, -0.4), elec="fenn", r_real=6.5, alpha=0.45, vel_T=300.0)
+        case.update(elec_type=2, ewald_k=(8, 5, 5))
     elif name == "hot":
         case = inputs.lj_case((14, 5, 5), a=5.4, seed=3, rc=7.0, cell_list=7.0, vel_T=4000.0)
     else:
@@ -94,7 +97,7 @@ def main():
         errs = {k: rel_err(merged[k], rs[k]) for k in keys if np.abs(rs[k]).max() > 0}
         out = {"world": world, "n_atoms": len(case["types"]), "owned_total": int(counts.item()),
                "every_atom_owned_once": bool((cover.numpy() == 1).all()), "max_rel_err_vs_single": max(errs.values()), "errs": errs,
-               "energy_rel": {k: abs(st[k] - rst[k]) / (abs(rst[k]) + 1e-300) for k in ("engTot", "engVdW", "engKin", "engCoul", "engTemp", "engBond", "engAngle") if abs(rst[k]) > 0},
+               "energy_rel": {k: abs(st[k] - rst[k]) / (abs(rst[k]) + 1e-300) for k in ("engTot", "engVdW", "engKin", "engCoul", "engTemp", "engBond", "engAngle", "engCoulRec", "engCoulConst") if abs(rst[k]) > 0},
                "cross": [st["negCross"], st["posCross"], rst["negCross"], rst["posCross"]],
                "mom_rel": rel_err(st["posMom"] + st["negMom"], rst["posMom"] + rst["negMom"]) if any(rst["posMom"] + rst["negMom"]) else 0.0}
         print("SLAB_RESULT " + json.dumps(out))

@@ -213,6 +213,84 @@ def test_bonded_input_files_and_energy_conservation(tmp_path):
     assert abs(e2 - e1) < 0.02 * abs(b.stats()["engKin"]), (e1, e2)      # bounded Verlet fluctuation (omega dt = 0.27 for the L-C stretch)
 
 
+# ---------------------------------------------------------------------------------------------------
+# Ewald sum ('elec pme'; "next" row f4)
+# ---------------------------------------------------------------------------------------------------
+def ewald_case(**kw):
+    c = inputs.lj_case((5, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5, charges=(0.4, -0.4), elec="fenn", r_real=6.5, alpha=0.45, vel_T=80.0)
+    c.update(elec_type=2, ewald_k=(6, 6, 6))
+    c.update(kw)
+    return c
+
+
+@pytest.mark.parametrize("kw", [{}, dict(ewald_k=(4, 7, 9)), dict(cell_list=3.4)])
+def test_ewald_forces_match_oracle(kw):
+    """reciprocal + real-space + constant parts of the Ewald sum against the oracle (forces 1e-11, energies 1e-12)."""
+    case = ewald_case(**kw)
+    o = oracle.Oracle(case)
+    o.forces(0)
+    so, sto = o.state(), o.stats()
+    e = engine(case, cell_size=kw.get("cell_list", 0.0))
+    s, st = e.state(), e.stats()
+    for k in FKEYS:
+        assert rel_err(s[k], so[k]) < 1e-11, (k, rel_err(s[k], so[k]))
+    for a, b in (("engCoulRec", "engElec2"), ("engCoulConst", "engElec1"), ("engCoul", "engElec3"), ("engVdW", "engVdW")):
+        assert abs(st[a] - sto[b]) <= 1e-12 * abs(sto[b]) + 1e-14, (a, st[a], sto[b])
+
+
+def test_ewald_anisotropic_box_with_tie_on_the_cutoff():
+    case = inputs.lj_case((6, 5, 4), a=5.4, seed=2, rc=5.2, cell_list=5.2, charges=(0.5, -0.5), elec="fenn", r_real=5.2, alpha=0.5, vel_T=200.0)
+    case.update(elec_type=2, ewald_k=(7, 5, 6))
+    o = oracle.Oracle(case)
+    o.forces(0)
+    e = engine(case)
+    for k in FKEYS:
+        assert rel_err(e.state()[k], o.state()[k]) < 1e-11
+    assert abs(e.stats()["engCoulRec"] - o.stats()["engElec2"]) < 1e-12 * abs(o.stats()["engElec2"])
+    e.step(25); o.step(25)
+    for k in ("x", "vx", "fx"):
+        assert rel_err(e.state()[k], o.state()[k]) < 1e-9, k
+
+
+def test_golden_ewald_trajectory(tmp_path):
+    """tests/golden/E1_ewald.npz (the reference's compiled ewald_rec in the loop), via the arrays and via 'elec pme' in control.txt."""
+    z = np.load(os.path.join(G, "E1_ewald.npz"))
+    case = ewald_case()
+    assert np.array_equal(case["x"], z["in_x"])
+    keys = EKEYS + ("engBond", "engAngle", "engElec1", "engElec2")
+    e = engine(case)
+    s0 = e.state()
+    for k in FKEYS:
+        assert rel_err(s0[k], z[k + "_0"]) < 1e-11
+    done = 0
+    for st in z["steps"].tolist()[1:]:
+        e.step(st - done)
+        done = st
+        stt = e.stats()
+        ref = dict(zip(keys, z["e_%d" % st].tolist()))
+        for a, b in (("engCoulRec", "engElec2"), ("engCoulConst", "engElec1"), ("engCoul", "engElec3"), ("engVdW", "engVdW"), ("engKin", "engKin"), ("engTot", "engTot")):
+            assert abs(stt[a] - ref[b]) <= 1e-10 * abs(ref[b]) + 1e-13, (st, a, stt[a], ref[b])
+    s = e.state()
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(s[k], z[k + "_40"]) < 1e-9, k
+    case0 = ewald_case(vx=np.zeros(500), vy=np.zeros(500), vz=np.zeros(500))
+    d = str(tmp_path / "pme")
+    inputs.write_input_files(case0, d)
+    a, b = api.Engine(api.Model.from_dir(d)), engine(case0)
+    a.step(20); b.step(20)
+    assert np.array_equal(a.state()["fx"], b.state()["fx"]) and a.stats()["engCoulRec"] == b.stats()["engCoulRec"]
+
+
+def test_ewald_graph_equals_eager_and_conserves_energy():
+    case = ewald_case()
+    a, b = engine(case, use_graph=1), engine(case, use_graph=0)
+    a.step(200); b.step(200)
+    assert np.array_equal(a.state()["x"], b.state()["x"])
+    e0 = a.stats()["engTot"]
+    a.step(800)
+    assert abs(a.stats()["engTot"] - e0) < 2e-2 * a.stats()["engKin"]        # truncation noise of rc 6.5 at alpha 0.45 (erfc(2.9) = 4e-5), not drift
+
+
 def test_wall_crossing_counters_and_field():
     """hot gas: atoms cross the periodic walls; wall momenta, crossing counts and field energy vs the oracle."""
     case = mixed_case("lnjs+fenn+field", vel_T=3000.0)

@@ -23,7 +23,7 @@ def run_ranks(nranks, name, nsteps, extra=None, port=29611):
 
 
 @pytest.mark.parametrize("nranks,name,nsteps,port", [(2, "lj", 40, 29611), (3, "fennel", 25, 29612), (4, "hot", 60, 29613), (2, "thermo", 20, 29614), (2, "nose", 15, 29616),
-                                                     (2, "mol", 60, 29617), (3, "mol", 30, 29618)])
+                                                     (2, "mol", 60, 29617), (3, "mol", 30, 29618), (2, "ewald", 30, 29619)])
 def test_slabs_match_single_rank(nranks, name, nsteps, port):
     out = run_ranks(nranks, name, nsteps, port=port)
     assert out["every_atom_owned_once"] and out["owned_total"] == out["n_atoms"]

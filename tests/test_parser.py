@@ -195,11 +195,46 @@ def test_missing_files_and_scope(tmp_path):
     assert "ERROR[001]" in str(ei.value)
     d = str(tmp_path / "pme")
     write_quirky(d)
-    open(os.path.join(d, "control.txt"), "w").write(QUIRKY_CONTROL.replace("elec\tfenn\t8.0\t0.4", "elec\tpme\t8.0\t0.4"))
+    open(os.path.join(d, "control.txt"), "w").write(QUIRKY_CONTROL.replace("elec\tfenn\t8.0\t0.4\t6\t6\t6", "elec\tpme\t8.0\t0.4\t0\t6\t6"))
     m = api.Model.from_dir(d)
-    with pytest.raises(api.AztotError) as ei:     # reciprocal-space Ewald is out of scope: rejected when the model is finished
+    with pytest.raises(api.AztotError) as ei:     # 'elec pme' needs at least one k-vector per axis
         m.query("rmax")
-    assert "out of scope" in str(ei.value)
+    assert "ERROR[404]" in str(ei.value)
+
+
+def test_ewald_directive(tmp_path):
+    """'elec pme rReal alpha kx ky kz' is the reference's plain Ewald sum (read_elec elec.cpp:33-38, prepare_elec :377-397):
+    constants, the k-vector list in ewald_rec's order and the constant energy term against the Python restatement."""
+    d = str(tmp_path / "ewald")
+    write_quirky(d)
+    open(os.path.join(d, "control.txt"), "w").write(QUIRKY_CONTROL.replace("elec\tfenn\t8.0\t0.4\t6\t6\t6", "elec\tpme\t8.0\t0.4\t5\t6\t7"))
+    m, o = compare(d)
+    assert o["elec_type"] == 2 and o["ewald_k"] == [5, 6, 7] and o["rmax"] == 8.0
+    ew = m.query("ewald")
+    assert [int(v) for v in ew[:3]] == [5, 6, 7] and int(ew[6]) == len(o["kvecs"]) > 100
+    assert ew[5] == pytest.approx(o["eng_elec1"], rel=1e-14)
+    kv = m.query("kvecs").reshape(-1, 7)
+    assert np.array_equal(kv[:, :3].astype(int), np.array([k[:3] for k in o["kvecs"]]))
+    assert np.allclose(kv[:, 3:], np.array([k[3:] for k in o["kvecs"]]), rtol=1e-15, atol=0)
+    assert tuple(kv[0, :3]) == (0, 0, 1) and kv[:, 0].min() == 0 and kv[:, 1].min() < 0 and kv[:, 2].min() < 0      # half space: l >= 0
+
+
+def test_ewald_kvector_on_the_cutoff_sphere(tmp_path):
+    """Box 6 x 5 x 4 lattice cells with k = (7, 5, 6): (l, m, n) = (6, 1, 1) has |k|^2 == rkcut^2 in exact arithmetic, so the
+    reference's rounding (ip1..3 through prepare_box's matrix algebra, box.cpp:92-151) decides - both parsers must follow it
+    (the live-reference oracle test pins the oracle on the same system)."""
+    case = inputs.lj_case((6, 5, 4), a=5.4, seed=2, rc=5.2, cell_list=5.2, charges=(0.5, -0.5), elec="fenn", r_real=5.2, alpha=0.5)
+    case.update(elec_type=2, ewald_k=(7, 5, 6))
+    d = str(tmp_path / "tie")
+    inputs.write_input_files(case, d)
+    m, o = compare(d)
+    kv = m.query("kvecs").reshape(-1, 7)[:, :3].astype(int).tolist()
+    assert kv == [list(k[:3]) for k in o["kvecs"]] and len(kv) == int(m.query("ewald")[6])
+    from oracle import oracle
+    orc = oracle.Oracle(case)
+    orc.forces(0)
+    e2 = orc.stats()["engElec2"]
+    assert abs(e2 - 1.2152744508039863) < 1e-12       # value of the reference binary (1.2048... if the tie falls the other way)
 
 
 REF = "/root/reference"
