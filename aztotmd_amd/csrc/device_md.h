@@ -59,10 +59,22 @@ struct EwaldK
     int32_t l, m, n, flags;          // flags: first k-vector with this l / with this (l, m)
     double rkx, rky, rkz, akk;       // rk[] and exprk2[] of cuInit.cu:1017-1046
 };
+struct EwaldW                        // work item of the structure-factor kernel: k-vectors (l, m, +n) and (l, m, -n)
+{
+    int32_t l, m, n;                 // n >= 0
+    int32_t kPlus, kMinus;           // indices into the k-vector table, -1 if that one is not in the sum
+};
+struct EwaldG                        // work item of the force kernel: the run of k-vectors (l, m, nLo..nHi), contiguous in the table
+{
+    int32_t l, m, nLo, nHi, kStart;
+};
 struct EwaldTables
 {
     const EwaldK* kv;
-    int32_t nK, kx, ky, kz, nBlocksA;
+    const EwaldW* work;
+    const EwaldG* groups;
+    double* T;                       // [nK][2]: scale2 * akk(k) * S(k), refreshed with S
+    int32_t nK, nW, nG, kx, ky, kz, nBlocksA;
     double* partial;                 // [nBlocksA][nK][2]: per-block partial structure factors
     double* S;                       // [nK][2]: (sum q cos kr, sum q sin kr) over ALL atoms
     double scale, scale2;            // elec.cpp:380-381

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
+#include <tuple>
 
 #include "exchange.h"
 #include "bonded.hip.h"
@@ -153,9 +154,10 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
     for (const auto& p : m.pairpots) if (p.type && p.use_radii) P_.use_radii = 1;
     P_.single_lj = (m.nSpec() == 1 && m.pairpots[0].type == AZTOT_VDW_LJ && m.elec_type == AZTOT_ELEC_NONE) ? 1 : 0;
     {   // kernel specialisation 2: few species, every pair potential Lennard-Jones (or absent), electrostatics none or Fennell
-        bool allLj = m.nSpec() <= 4 && !P_.single_lj && (m.elec_type == AZTOT_ELEC_NONE || m.elec_type == AZTOT_ELEC_FENNEL);
+        bool allLj = m.nSpec() <= 4 && !P_.single_lj &&
+                     (m.elec_type == AZTOT_ELEC_NONE || m.elec_type == AZTOT_ELEC_FENNEL || m.elec_type == AZTOT_ELEC_EWALD);
         for (const auto& p : m.pairpots) if (p.type != 0 && p.type != AZTOT_VDW_LJ) allLj = false;
-        if (m.elec_type == AZTOT_ELEC_FENNEL && m.alpha * m.rReal > 4.0) allLj = false;      // range of erfc_given_exp
+        if ((m.elec_type == AZTOT_ELEC_FENNEL || m.elec_type == AZTOT_ELEC_EWALD) && m.alpha * m.rReal > 4.0) allLj = false;   // range of erfc_given_exp
         P_.pad1 = allLj ? 2 : 0;
     }
     std::memset(&S_, 0, sizeof(S_));
@@ -332,6 +334,30 @@ void Engine::upload_ewald()
     EwaldK* dkv = (EwaldK*)alloc(sizeof(EwaldK) * kv.size());
     HIP_CHECK(hipMemcpy(dkv, kv.data(), sizeof(EwaldK) * kv.size(), hipMemcpyHostToDevice));
     ew_.kv = dkv;
+    // work items of k_ewald_sfac: (l, m, |n|) with the indices of its +n / -n members
+    std::map<std::tuple<int, int, int>, int> slot;
+    std::vector<EwaldW> work;
+    for (size_t k = 0; k < kv.size(); k++)
+    {
+        const auto key = std::make_tuple(kv[k].l, kv[k].m, std::abs(kv[k].n));
+        auto it = slot.find(key);
+        if (it == slot.end()) { slot[key] = (int)work.size(); work.push_back(EwaldW{kv[k].l, kv[k].m, std::abs(kv[k].n), -1, -1}); it = slot.find(key); }
+        if (kv[k].n >= 0) work[it->second].kPlus = (int)k; else work[it->second].kMinus = (int)k;
+    }
+    EwaldW* dw = (EwaldW*)alloc(sizeof(EwaldW) * work.size());
+    HIP_CHECK(hipMemcpy(dw, work.data(), sizeof(EwaldW) * work.size(), hipMemcpyHostToDevice));
+    ew_.work = dw; ew_.nW = (int)work.size();
+    // work items of k_ewald_force: runs of consecutive n with the same (l, m) (the table is in ewald_rec's nested-loop order)
+    std::vector<EwaldG> groups;
+    for (size_t k = 0; k < kv.size(); k++)
+    {
+        if (!groups.empty() && groups.back().l == kv[k].l && groups.back().m == kv[k].m && groups.back().nHi + 1 == kv[k].n) groups.back().nHi = kv[k].n;
+        else groups.push_back(EwaldG{kv[k].l, kv[k].m, kv[k].n, kv[k].n, (int)k});
+    }
+    EwaldG* dg = (EwaldG*)alloc(sizeof(EwaldG) * groups.size());
+    HIP_CHECK(hipMemcpy(dg, groups.data(), sizeof(EwaldG) * groups.size(), hipMemcpyHostToDevice));
+    ew_.groups = dg; ew_.nG = (int)groups.size();
+    ew_.T = (double*)alloc(sizeof(double) * 2 * kv.size());
     ew_.nK = (int)kv.size(); ew_.kx = m.ewald_k[0]; ew_.ky = m.ewald_k[1]; ew_.kz = m.ewald_k[2];
     ew_.nBlocksA = std::max(1, std::min(1024, div_up(capacity_, kEwTile)));
     ew_.partial = (double*)alloc(sizeof(double) * 2 * (size_t)ew_.nK * ew_.nBlocksA);
@@ -351,12 +377,13 @@ void Engine::launch_ewald()
     const size_t lds = sizeof(double) * 2 * (size_t)kEwTile * (ew_.kx + ew_.ky + ew_.kz);
     timed("ewald_sfac", [&] {
         hipLaunchKernelGGL(k_ewald_sfac, dim3(ew_.nBlocksA), dim3(256), lds, stream_, P_, S_, cur(), dCounts_, ew_);
-        hipLaunchKernelGGL(k_ewald_reduce, dim3(div_up(ew_.nK, 256)), dim3(256), 0, stream_, ew_);
+        hipLaunchKernelGGL(k_ewald_reduce, dim3(div_up(ew_.nK, 64)), dim3(64 * kEwRedGroups), 0, stream_, ew_);
     });
     if (nranks_ > 1) timed("ewald_allreduce", [&] { xch_->allreduce_device(ew_.S, 2 * ew_.nK, stream_); });
+    timed("ewald_energy", [&] { hipLaunchKernelGGL(k_ewald_energy, dim3(1), dim3(256), 0, stream_, ew_, dStats_); });
     timed("ewald_force", [&] {
-        hipLaunchKernelGGL(k_ewald_energy, dim3(1), dim3(256), 0, stream_, ew_, dStats_);
-        hipLaunchKernelGGL(k_ewald_force, dim3(div_up(capacity_, kEwTile)), dim3(kEwTile), lds, stream_, P_, S_, cur(), dCounts_, ew_);
+        hipLaunchKernelGGL(k_ewald_force, dim3(div_up(capacity_, kEwTile)), dim3(kEwTile * kEwSlices), lds + sizeof(double) * 3 * kEwTile * kEwSlices,
+                           stream_, P_, S_, cur(), dCounts_, ew_);
     });
 }
 

@@ -38,6 +38,8 @@ __device__ __forceinline__ void ew_harmonics(double arg, int n, cplx* out, int s
     }
 }
 
+// work item of k_ewald_sfac: the pair of k-vectors (l, m, +n), (l, m, -n) - they share exp(i(lx + my)) and, up to conjugation,
+// exp(inz), which halves the LDS traffic per k-vector - or a single one (n == 0, or l == m == 0 where only n >= 1 is visited)
 __global__ __launch_bounds__(256) void k_ewald_sfac(StepParams P, SpecTable S, AtomArrays A, const Counts* __restrict__ cnt, EwaldTables E)
 {
     extern __shared__ double ew_lds[];
@@ -53,52 +55,77 @@ __global__ __launch_bounds__(256) void k_ewald_sfac(StepParams P, SpecTable S, A
         const int nAt = max(0, min(kEwTile, nOwned - base));
         __syncthreads();
         if (threadIdx.x < 3 * kEwTile)
-        {   // one thread per (atom, axis): that axis' harmonics; the charge rides on the x-table
+        {   // one thread per (atom, axis): that axis' harmonics; the charge rides on the x-table; the tile is padded with
+            // zero-charge atoms so that the accumulation loop below has a constant trip count
             const int a = threadIdx.x % kEwTile, ax = threadIdx.x / kEwTile;
-            if (a < nAt)
-            {
-                const int i = cnt->ownedBegin + base + a;
-                cplx* row = tab + a * nH;
-                if (ax == 0) ew_harmonics(twopi * A.x[i] * P.invL[0], E.kx, row, 1, S.charge[A.type[i]]);
-                else if (ax == 1) ew_harmonics(twopi * A.y[i] * P.invL[1], E.ky, row + E.kx, 1, 1.0);
-                else ew_harmonics(twopi * A.z[i] * P.invL[2], E.kz, row + E.kx + E.ky, 1, 1.0);
-            }
+            cplx* row = tab + a * nH;
+            const int i = cnt->ownedBegin + base + min(a, max(nAt - 1, 0));
+            const bool real = a < nAt;
+            if (ax == 0) ew_harmonics(real ? twopi * A.x[i] * P.invL[0] : 0.0, E.kx, row, 1, real ? S.charge[A.type[i]] : 0.0);
+            else if (ax == 1) ew_harmonics(real ? twopi * A.y[i] * P.invL[1] : 0.0, E.ky, row + E.kx, 1, 1.0);
+            else ew_harmonics(real ? twopi * A.z[i] * P.invL[2] : 0.0, E.kz, row + E.kx + E.ky, 1, 1.0);
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < E.nK; k += blockDim.x)
+        for (int w = threadIdx.x; w < E.nW; w += blockDim.x)
         {
-            const EwaldK kv = E.kv[k];
-            const int io = kv.l, im = E.kx + abs(kv.m), in = E.kx + E.ky + abs(kv.n);
-            const double sm = kv.m < 0 ? -1.0 : 1.0, sn = kv.n < 0 ? -1.0 : 1.0;
-            double sc = 0.0, ss = 0.0;
-            for (int a = 0; a < nAt; a++)
+            const EwaldW wi = E.work[w];
+            const cplx* px = tab + wi.l;
+            const cplx* pm = tab + E.kx + abs(wi.m);
+            const cplx* pn = tab + E.kx + E.ky + wi.n;
+            const double sm = wi.m < 0 ? -1.0 : 1.0;
+            double pc = 0.0, ps = 0.0, mc = 0.0, ms = 0.0;      // sums for +n and -n
+#pragma unroll 8
+            for (int a = 0; a < kEwTile; a++)
             {
-                const cplx* row = tab + a * nH;
-                const cplx ex = row[io];
-                cplx em = row[im], en = row[in];
-                em.s *= sm; en.s *= sn;                         // negative m / n: complex conjugate (elec.cpp:258-262,296-307)
-                const cplx ck = cmul(cmul(ex, em), en);
-                sc += ck.c; ss += ck.s;
+                const cplx ex = px[a * nH];
+                cplx em = pm[a * nH];
+                const cplx en = pn[a * nH];
+                em.s *= sm;                                     // negative m: complex conjugate (elec.cpp:258-262)
+                const cplx lm = cmul(ex, em);
+                const double cc = lm.c * en.c, ss = lm.s * en.s, sc = lm.s * en.c, cs = lm.c * en.s;
+                pc += cc - ss; ps += sc + cs;                   // (l, m, +n): elec.cpp:287-288
+                mc += cc + ss; ms += sc - cs;                   // (l, m, -n): conjugate of exp(inz), elec.cpp:300-301
             }
-            if (it == 0) { mine[2 * k] = sc; mine[2 * k + 1] = ss; }
-            else { mine[2 * k] += sc; mine[2 * k + 1] += ss; }
+            if (wi.kPlus >= 0)
+            {
+                if (it == 0) { mine[2 * wi.kPlus] = pc; mine[2 * wi.kPlus + 1] = ps; }
+                else { mine[2 * wi.kPlus] += pc; mine[2 * wi.kPlus + 1] += ps; }
+            }
+            if (wi.kMinus >= 0)
+            {
+                if (it == 0) { mine[2 * wi.kMinus] = mc; mine[2 * wi.kMinus + 1] = ms; }
+                else { mine[2 * wi.kMinus] += mc; mine[2 * wi.kMinus + 1] += ms; }
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_ewald_reduce(EwaldTables E)
+// S(k) = sum over the blocks' partial rows, fixed order: 64 k-vectors x 16 row groups per workgroup (coalesced 1 KB row
+// segments), the 16 group sums folded through LDS in group order
+constexpr int kEwRedGroups = 16;
+__global__ __launch_bounds__(64 * kEwRedGroups) void k_ewald_reduce(EwaldTables E)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= E.nK) return;
+    __shared__ double red[kEwRedGroups][64][2];
+    const int kl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
     double sc = 0.0, ss = 0.0;
-    for (int b = 0; b < E.nBlocksA; b++)
+    if (k < E.nK)
+        for (int b = g; b < E.nBlocksA; b += kEwRedGroups)
+        {
+            const double* row = E.partial + ((size_t)b * E.nK + k) * 2;
+            sc += row[0]; ss += row[1];
+        }
+    red[g][kl][0] = sc; red[g][kl][1] = ss;
+    __syncthreads();
+    if (g == 0 && k < E.nK)
     {
-        const double* row = E.partial + ((size_t)b * E.nK + k) * 2;
-        sc += row[0]; ss += row[1];
+        double c = 0.0, s2 = 0.0;
+        for (int q = 0; q < kEwRedGroups; q++) { c += red[q][kl][0]; s2 += red[q][kl][1]; }
+        E.S[2 * k] = c; E.S[2 * k + 1] = s2;
     }
-    E.S[2 * k] = sc; E.S[2 * k + 1] = ss;
 }
 
+// E = scale * sum_k akk |S(k)|^2, and the per-k factors of the force kernel: T(k) = scale2 * akk * S(k)
 __global__ __launch_bounds__(256) void k_ewald_energy(EwaldTables E, DevStats* st)
 {
     __shared__ double scratch[4];
@@ -106,50 +133,85 @@ __global__ __launch_bounds__(256) void k_ewald_energy(EwaldTables E, DevStats* s
     for (int k = threadIdx.x; k < E.nK; k += blockDim.x)
     {
         const double sc = E.S[2 * k], ss = E.S[2 * k + 1];
-        e += E.kv[k].akk * (sc * sc + ss * ss);
+        const double akk = E.kv[k].akk;
+        e += akk * (sc * sc + ss * ss);
+        E.T[2 * k] = (akk * E.scale2) * sc; E.T[2 * k + 1] = (akk * E.scale2) * ss;
     }
     e = block_sum(e, scratch);
     if (threadIdx.x == 0) st->engCoulRec = E.scale * e;         // engElec2, elec.cpp:333
 }
 
-__global__ __launch_bounds__(kEwTile) void k_ewald_force(StepParams P, SpecTable S, AtomArrays A, const Counts* __restrict__ cnt, EwaldTables E)
+// Forces.  KS waves per block share one tile of 64 atoms (lane <-> atom); wave `slice` takes every KS-th (l, m) group of the
+// k-vector list, so the chip sees KS x nAtoms/64 waves.  Inside a group n runs over a contiguous range: exp(i(lx + my)) is
+// formed once, rkx and rky are constant, rkz = n * 2pi/c - per k-vector one LDS read (exp(inz)), one 16-byte scalar load
+// (T(k)), a complex product and 4 more flops:  x = Im(conj(T) q e^{ikr}) ; F += (rkx, rky, n 2pi/c) x   (elec.cpp:317-322)
+constexpr int kEwSlices = 8;
+
+__global__ __launch_bounds__(kEwTile* kEwSlices) void k_ewald_force(StepParams P, SpecTable S, AtomArrays A, const Counts* __restrict__ cnt,
+                                                                     EwaldTables E)
 {
     extern __shared__ double ew_lds[];
     cplx* tab = (cplx*)ew_lds;                                  // [nH][kEwTile]
-    const int lane = threadIdx.x;
-    const int i = cnt->ownedBegin + blockIdx.x * kEwTile + lane;
-    const bool valid = i < cnt->ownedEnd;
+    const int nH = E.kx + E.ky + E.kz;
+    double* red = ew_lds + 2 * (size_t)nH * kEwTile;            // [kEwSlices][3][kEwTile]
+    const int lane = threadIdx.x & (kEwTile - 1);
+    const int slice = __builtin_amdgcn_readfirstlane(threadIdx.x / kEwTile);     // wave-uniform: keeps the k loops on scalar registers
+    const int i0 = cnt->ownedBegin + blockIdx.x * kEwTile;
     const double twopi = 2.0 * 3.14159265359;
-    if (valid)
+    if (threadIdx.x < 3 * kEwTile)
     {
-        ew_harmonics(twopi * A.x[i] * P.invL[0], E.kx, tab + lane, kEwTile, S.charge[A.type[i]]);
-        ew_harmonics(twopi * A.y[i] * P.invL[1], E.ky, tab + E.kx * kEwTile + lane, kEwTile, 1.0);
-        ew_harmonics(twopi * A.z[i] * P.invL[2], E.kz, tab + (E.kx + E.ky) * kEwTile + lane, kEwTile, 1.0);
+        const int a = threadIdx.x % kEwTile, ax = threadIdx.x / kEwTile;
+        const bool real = i0 + a < cnt->ownedEnd;
+        const int i = real ? i0 + a : cnt->ownedBegin;
+        if (ax == 0) ew_harmonics(real ? twopi * A.x[i] * P.invL[0] : 0.0, E.kx, tab + a, kEwTile, real ? S.charge[A.type[i]] : 0.0);
+        else if (ax == 1) ew_harmonics(real ? twopi * A.y[i] * P.invL[1] : 0.0, E.ky, tab + E.kx * kEwTile + a, kEwTile, 1.0);
+        else ew_harmonics(real ? twopi * A.z[i] * P.invL[2] : 0.0, E.kz, tab + (E.kx + E.ky) * kEwTile + a, kEwTile, 1.0);
     }
-    else
-        for (int h = 0; h < E.kx + E.ky + E.kz; h++) tab[h * kEwTile + lane] = cplx{0.0, 0.0};
-    // a lane only ever reads its own column: no barrier needed
+    __syncthreads();
     double fx = 0.0, fy = 0.0, fz = 0.0;
-    cplx ex = cplx{0.0, 0.0}, lm = cplx{0.0, 0.0};
     const cplx* tm = tab + E.kx * kEwTile + lane;
     const cplx* tn = tab + (E.kx + E.ky) * kEwTile + lane;
-    for (int k = 0; k < E.nK; k++)
+    const double* __restrict__ T = E.T;
+    for (int g = slice; g < E.nG; g += kEwSlices)
     {
-        const EwaldK kv = E.kv[k];                              // wave-uniform: scalar loads
-        if (kv.flags & EWK_NEW_L) ex = tab[kv.l * kEwTile + lane];
-        if (kv.flags & EWK_NEW_LM)
+        const EwaldG G = E.groups[g];                           // wave-uniform: scalar load
+        const cplx ex = tab[G.l * kEwTile + lane];
+        cplx em = tm[abs(G.m) * kEwTile];
+        if (G.m < 0) em.s = -em.s;
+        const cplx lm = cmul(ex, em);
+        double sx = 0.0, sz = 0.0;
+        const double* Tg = T + 2 * (size_t)(G.kStart - G.nLo);
+#pragma unroll 4
+        for (int n = G.nLo; n <= G.nHi; n++)
         {
-            cplx em = tm[abs(kv.m) * kEwTile];
-            if (kv.m < 0) em.s = -em.s;
-            lm = cmul(ex, em);
+            cplx en = tn[abs(n) * kEwTile];
+            if (n < 0) en.s = -en.s;
+            const cplx ck = cmul(lm, en);
+            const double x = ck.s * Tg[2 * n] - ck.c * Tg[2 * n + 1];
+            sx += x;
+            sz = fma((double)n, x, sz);
         }
-        cplx en = tn[abs(kv.n) * kEwTile];
-        if (kv.n < 0) en.s = -en.s;
-        const cplx ck = cmul(lm, en);
-        const double x = (kv.akk * E.scale2) * (ck.s * E.S[2 * k] - ck.c * E.S[2 * k + 1]);   // elec.cpp:317-319
-        fx = fma(kv.rkx, x, fx); fy = fma(kv.rky, x, fy); fz = fma(kv.rkz, x, fz);
+        fx = fma((double)G.l * (twopi * P.invL[0]), sx, fx);
+        fy = fma((double)G.m * (twopi * P.invL[1]), sx, fy);
+        fz += sz;
     }
-    if (valid) { A.fx[i] += fx; A.fy[i] += fy; A.fz[i] += fz; }
+    fz *= twopi * P.invL[2];
+    red[(slice * 3 + 0) * kEwTile + lane] = fx;
+    red[(slice * 3 + 1) * kEwTile + lane] = fy;
+    red[(slice * 3 + 2) * kEwTile + lane] = fz;
+    __syncthreads();
+    if (threadIdx.x < 3 * kEwTile)
+    {
+        const int a = threadIdx.x % kEwTile, c = threadIdx.x / kEwTile;
+        double f = 0.0;
+        for (int sl = 0; sl < kEwSlices; sl++) f += red[(sl * 3 + c) * kEwTile + a];
+        const int i = i0 + a;
+        if (i < cnt->ownedEnd)
+        {
+            double* dst = (c == 0) ? A.fx : (c == 1 ? A.fy : A.fz);
+            dst[i] += f;
+        }
+    }
 }
 
 }  // namespace aztot

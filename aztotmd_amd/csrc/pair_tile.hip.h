@@ -180,7 +180,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 const double fm = tooBig ? 0.0 : f;
                 acc.fx = fma(fm, dx, acc.fx); acc.fy = fma(fm, dy, acc.fy); acc.fz = fma(fm, dz, acc.fz);
             }
-            else if (MODE == 2)
+            else if (MODE >= 2)
             {   // every species pair is Lennard-Jones (fer_lj vdw.cpp:16-26), electrostatics none or Fennell/DSF (fennel
                 // elec.cpp:430-444); parameters per species pair come from a small LDS table: {p0, p1, p2, r2cut, kqq}
                 const double* pp = pairTab + (ti * P.nSpec + ttyp[k]) * 5;
@@ -192,7 +192,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 const double sr6 = sr2 * sr2 * sr2;
                 acc.eV = fma(0.5 * pp[0], sr6 * (sr6 - 1.0), acc.eV);
                 double f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
-                if (P.elec_type == 3)
+                if (MODE == 2 && P.elec_type == 3)
                 {
                     const double kqq = pairOk ? pp[4] : 0.0;
                     const double r = sqrt(r2s), ir = r * r2i;
@@ -201,6 +201,16 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                     const double erfcar = erfc_given_exp(ar, ex);
                     acc.eC = fma(0.5 * kqq, erfcar * ir - P.el_scale + P.el_scale2 * (r - P.rReal), acc.eC);
                     f = fma(kqq * ir, (erfcar * r2i + P.daipi2 * ex * ir) - P.el_scale2, f);
+                }
+                else if (MODE == 3)
+                {   // real-space term of the Ewald sum: coul_iter elec.cpp:344-369 (real_ewald cuElec.cu:94-113)
+                    const double kqq = pairOk ? pp[4] : 0.0;
+                    const double r = sqrt(r2s), ir = r * r2i;
+                    const double ar = P.alpha * r;
+                    const double ex = exp(-ar * ar);
+                    const double erfcar = erfc_given_exp(ar, ex);
+                    acc.eC = fma(0.5 * kqq, erfcar * ir, acc.eC);
+                    f = fma(kqq * ir * r2i, fma(P.daipi2 * r, ex, erfcar), f);
                 }
                 const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
                 nDropHalf += __popcll(__ballot(tooBig));
@@ -215,15 +225,16 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
     if (MODE != 0 && threadIdx.x == 0) acc.dropped += 0.5 * (double)nDropHalf;
 }
 
-template <int MODE>   // 0: generic (any potential, Coulomb, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, all LJ, elec none|Fennell
-__global__ __launch_bounds__(kWave, MODE == 2 ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
+template <int MODE>   // 0: generic (any potential, Coulomb, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, all LJ, elec none|Fennell ;
+                      // 3: as 2 with the real-space term of the Ewald sum
+__global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks)
 {
     __shared__ double tx[kTileLds], ty[kTileLds], tz[kTileLds];
     __shared__ int32_t ttyp[MODE != 1 ? kTileLds : 1];
     __shared__ double trad[MODE == 0 ? kTileLds : 1];
-    __shared__ double pairTab[MODE == 2 ? kLjSpecMax * kLjSpecMax * 5 : 1];
+    __shared__ double pairTab[MODE >= 2 ? kLjSpecMax * kLjSpecMax * 5 : 1];
     __shared__ int32_t entJ[kWave], entN[kWave], entC[kWave];       // staging table: first atom, count (<= 64), image-shift code
 
     const int lane = threadIdx.x;
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(kWave, MODE == 2 ? 3 : 1) void k_pair_tile(StepPara
         const double lo0 = (lx + P.cx0) * P.csz[0], lo1 = cy * P.csz[1], lo2 = cz * P.csz[2];
         const double hi0 = lo0 + P.csz[0], hi1 = lo1 + P.csz[1], hi2 = lo2 + P.csz[2];
         const DevPot lj = pots[0];
-        if (MODE == 2)
+        if (MODE >= 2)
         {
             const int np = P.nSpec * P.nSpec;
             if (lane < np)
@@ -441,6 +452,8 @@ inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevP
     const int grid = pair_tile_grid(P);
     if (P.single_lj)
         hipLaunchKernelGGL(k_pair_tile<1>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
+    else if (P.pad1 == 2 && P.elec_type == 2)
+        hipLaunchKernelGGL(k_pair_tile<3>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
     else if (P.pad1 == 2)
         hipLaunchKernelGGL(k_pair_tile<2>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
     else

@@ -247,6 +247,10 @@ def config(name):
         return lj_case((63, 63, 63), seed=20240502, charges=(0.2, -0.2), elec="fenn")
     if name == "C4":      # 1 000 188 atoms, pure LJ
         return lj_case((63, 63, 63), seed=20240502)
+    if name == "E2":      # 40 000 ions, LJ + full Ewald sum ('elec pme 8.5 0.35 12 12 14'; "next" row f4)
+        c = lj_case((20, 20, 25), seed=20240504, charges=(0.2, -0.2), elec="fenn", r_real=8.5, alpha=0.35)
+        c.update(elec_type=2, ewald_k=(12, 12, 14))
+        return c
     if name == "M4":      # 1 029 000 atoms: 343 000 bent triatomics (bonds + angles), LJ + Fennell  ("next" row f2)
         return molecular_case((70, 70, 70), seed=20240503, charges=(-0.2, 0.1), elec="fenn", quantize=False)
     raise KeyError(name)
