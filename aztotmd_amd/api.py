@@ -85,7 +85,7 @@ SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
 
 EXPORTS = ("aztot_init_md", "aztot_model_create", "aztot_model_set_bonded", "aztot_model_query", "aztot_model_species_name", "aztot_free_md", "aztot_default_options",
-           "aztot_init_device", "aztot_free_device", "aztot_step", "aztot_forces", "aztot_get_stats", "aztot_md_to_host",
+           "aztot_init_device", "aztot_free_device", "aztot_step", "aztot_forces", "aztot_get_stats", "aztot_species_crossings", "aztot_md_to_host",
            "aztot_set_state", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id",
            "aztot_init_device_slab", "aztot_last_error", "aztot_version")
 
@@ -134,6 +134,7 @@ def lib():
         L.aztot_step.argtypes = [C.c_void_p, C.c_int]
         L.aztot_forces.argtypes = [C.c_void_p]
         L.aztot_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
+        L.aztot_species_crossings.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
         L.aztot_md_to_host.argtypes = [C.c_void_p, C.POINTER(_State)]
         L.aztot_set_state.argtypes = [C.c_void_p, C.POINTER(_State)]
         L.aztot_kernel_times.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.POINTER(C.c_int64), C.c_int]
@@ -327,6 +328,13 @@ class Engine:
             v = getattr(s, k)
             d[k] = list(v) if hasattr(v, "__len__") else v
         return d
+
+    def species_crossings(self):
+        """(n_species, 6) int array: crossings of the walls Xn, Xp, Yn, Yp, Zn, Zp per species (the columns of msd.dat)."""
+        ns = int(self.model.query("n_species")[0])
+        out = np.zeros(6 * ns, dtype=np.int64)
+        _check(lib().aztot_species_crossings(self.h, out.ctypes.data_as(C.POINTER(C.c_int64)), out.size))
+        return out.reshape(ns, 6)
 
     def state(self, keys=("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz", "U", "radius")):
         """Per-atom arrays in ORIGINAL atom order.  On a slab rank only the owned atoms are filled (others NaN)."""

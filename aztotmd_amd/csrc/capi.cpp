@@ -254,6 +254,12 @@ int aztot_get_stats(aztot_md* md, aztot_stats* out)
     return guarded([&] { md->eng->get_stats(*out); });
 }
 
+int aztot_species_crossings(aztot_md* md, int64_t* out, int cap)
+{
+    if (!md || !md->eng || !out) return fail(AZTOT_ERR_ARG, "null argument");
+    return guarded([&] { md->eng->species_crossings(out, cap); });
+}
+
 int aztot_md_to_host(aztot_md* md, aztot_state* out)
 {
     if (!md || !out) return fail(AZTOT_ERR_ARG, "null argument");

@@ -136,6 +136,7 @@ struct DevStats
     double ekSim;                 // the reference's sim->engKin as the thermostats see it (value left by the previous integrate2)
     double chit, conint;          // Nose-Hoover friction and conserved-quantity integral (temperature.h:24-25)
     double local[PS_COUNT];       // this rank's per-step sums before the cross-rank reduction
+    unsigned long long specCross[kSpecCap * 6];   // per species: crossings of the walls Xn, Xp, Yn, Yp, Zn, Zp (specAcBoxNeg/Pos, cuStruct.h)
 };
 
 }  // namespace aztot

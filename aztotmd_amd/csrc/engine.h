@@ -39,6 +39,7 @@ public:
     void step(int nsteps);
     void forces(bool withBonded = true);    // sort + pair forces (+ bonds / angles) on the current positions
     void get_stats(aztot_stats& out);
+    void species_crossings(int64_t* out, int cap);
     void md_to_host(aztot_state& out);
     void set_state(const aztot_state& in);
     int kernel_times(std::vector<KernelTimer>& out);

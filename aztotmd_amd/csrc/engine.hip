@@ -656,6 +656,19 @@ void Engine::get_stats(aztot_stats& out)
     out.pressure = pressure_;
 }
 
+void Engine::species_crossings(int64_t* out, int cap)
+{
+    const int n = 6 * model_.nSpec();
+    if (cap < n) throw std::runtime_error("species_crossings: output array too small");
+    sync();
+    DevStats s;
+    HIP_CHECK(hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost));
+    double v[kSpecCap * 6];
+    for (int k = 0; k < n; k++) v[k] = (double)s.specCross[k];
+    if (nranks_ > 1) xch_->allreduce_sum(v, n, stream_);
+    for (int k = 0; k < n; k++) out[k] = (int64_t)(v[k] + 0.5);
+}
+
 // md_to_host (cuInit.cu:1212-1262).  The reference returns the arrays in cell-sorted order (SURVEY C-20);
 // we put every atom back at its original index.  On several ranks each rank fills only the atoms it owns.
 void Engine::md_to_host(aztot_state& out)

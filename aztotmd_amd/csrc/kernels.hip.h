@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
                                                            int32_t* __restrict__ cellOf, int32_t* __restrict__ slotOf,
                                                            int32_t* __restrict__ cellCount, double* __restrict__ partials, int maxBlocks,
                                                            MsgLayout lay, char* __restrict__ sendLeft, char* __restrict__ sendRight,
-                                                           const DevStats* __restrict__ st)
+                                                           DevStats* __restrict__ st)
 {
     __shared__ double scratch[kBlock / kWave];
     const int begin = cnt->ownedBegin, end = cnt->ownedEnd;
@@ -274,6 +274,12 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
             if (c < 0) { mom[2] = m * (-vy); cross[2] = 1; anyCross = 1; } else if (c > 0) { mom[3] = m * vy; cross[3] = 1; anyCross = 1; }
             c = wrap_coord(z, P.L[2], P.invL[2]);
             if (c < 0) { mom[4] = m * (-vz); cross[4] = 1; anyCross = 1; } else if (c > 0) { mom[5] = m * vz; cross[5] = 1; anyCross = 1; }
+            if (anyCross)
+            {   // per-species crossing counters: specAcBoxNeg / specAcBoxPos of put_periodic (cuMDfunc.cu:35-106), the columns of
+                // msd.dat.  Crossings are rare (a few atoms per step), so plain global atomics cost nothing.
+#pragma unroll
+                for (int d = 0; d < 6; d++) if (cross[d] != 0.0) atomicAdd(&st->specCross[t * 6 + d], 1ULL);
+            }
             A.vx[i] = vx; A.vy[i] = vy; A.vz[i] = vz;
             A.x[i] = x; A.y[i] = y; A.z[i] = z;
             eField = S.charge[t] * (x * P.E[0] + y * P.E[1] + z * P.E[2]);      // integrators.cpp:374 / cuMDfunc.cu:476

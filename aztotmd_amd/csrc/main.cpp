@@ -74,6 +74,14 @@ int main(int argc, char** argv)
     std::fprintf(sf, "time, ps\tstep, n\tengTot, eV\tengKin, eV\tengVdW, eV\tengCoul1, eV\tengCoul2, eV%s%s%s"
                      "\tmomPx, eVps/A\tmomNx, eVps/A\tmomPy, eVps/A\tmomNy, eVps/A\tmomPz, eVps/A\tmomNz, eVps/A\tpress, atm\n", radi ? "\tengTerm, eV" : "",
                  hasB ? "\tengBnd, eV" : "", hasA ? "\tengAngle, eV" : "");
+    // msd.dat: despite its name the reference writes the per-species wall-crossing counters there (start_stat cuStat.cu:345-350,
+    // init_cuda_stat :278-288: specAcBoxPos/Neg x, y, z per species), one row per statistics step
+    FILE* mf = std::fopen((out + "/msd.dat").c_str(), "w");
+    if (!mf) { std::perror("msd.dat"); return 1; }
+    std::fprintf(mf, "time\tstep");
+    for (int j = 0; j < nSpec; j++) std::fprintf(mf, "\t%s_px\tnx\tpy\tny\tpz\tnz", names[j].c_str());
+    std::fprintf(mf, "\n");
+    std::vector<int64_t> crossings(6 * (size_t)nSpec);
     aztot_stats st;
     for (int done = 0; done < nStep;)
     {
@@ -86,9 +94,16 @@ int main(int argc, char** argv)
         if (hasB) std::fprintf(sf, "\t%f", st.engBond);
         if (hasA) std::fprintf(sf, "\t%f", st.engAngle);
         std::fprintf(sf, "\t%f\t%f\t%f\t%f\t%f\t%f\t%f\n", st.posMom[0], st.negMom[0], st.posMom[1], st.negMom[1], st.posMom[2], st.negMom[2], st.pressure);
+        if (aztot_species_crossings(md, crossings.data(), (int)crossings.size()) != AZTOT_OK) die("species crossings");
+        std::fprintf(mf, "%f\t%d", st.time, (int)st.step);
+        for (int j = 0; j < nSpec; j++)        // our slots are Xn, Xp, Yn, Yp, Zn, Zp; the file wants px nx py ny pz nz
+            std::fprintf(mf, "\t%lld\t%lld\t%lld\t%lld\t%lld\t%lld", (long long)crossings[6 * j + 1], (long long)crossings[6 * j + 0],
+                         (long long)crossings[6 * j + 3], (long long)crossings[6 * j + 2], (long long)crossings[6 * j + 5], (long long)crossings[6 * j + 4]);
+        std::fprintf(mf, "\n");
         std::printf("time=%f(%d) Tot=%f Kin=%f VdW=%f Coul=%f T=%f P=%f\n", st.time, (int)st.step, st.engTot, st.engKin, st.engVdW, st.engCoul, st.temperature, st.pressure);
     }
     std::fclose(sf);
+    std::fclose(mf);
 
     std::vector<double> x(N), y(N), z(N), vx(N), vy(N), vz(N), U(N), rad(N);
     std::vector<int32_t> types(N);

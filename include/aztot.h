@@ -185,6 +185,10 @@ int aztot_step(aztot_md *md, int nsteps);
 /* cell-list build + sort + pair forces for the current positions: iter_fastCellList (cuPairs.h:8) alone */
 int aztot_forces(aztot_md *md);
 int aztot_get_stats(aztot_md *md, aztot_stats *out);
+/* per-species wall crossings since init: out[6 * s + {0..5}] = species s through the walls Xn, Xp, Yn, Yp, Zn, Zp - the
+   specAcBoxNeg / specAcBoxPos counters of put_periodic (cuMDfunc.cu:35-106) that the reference writes to msd.dat
+   (cuStat.cu:278-288,345-350).  cap = number of int64 slots in out (>= 6 * n_species).  Collective on several ranks. */
+int aztot_species_crossings(aztot_md *md, int64_t *out, int cap);
 int aztot_md_to_host(aztot_md *md, aztot_state *out);
 int aztot_set_state(aztot_md *md, const aztot_state *in);
 

@@ -83,6 +83,7 @@ typedef struct
     double engVdW, engElec3, engKin, engTot, engElecField, engTemp, TempNow;
     double mom[6];                                       /* Xn, Xp, Yn, Yp, Zn, Zp: box.cpp:230-295 */
     long long cross[6];
+    long long specCross[16 * 6];                         /* per species: specAcBoxNeg/Pos of put_periodic, cuMDfunc.cu:35-106 (msd.dat) */
     long long nDropped;                                  /* pairs dropped by the f^2 > 1e10 rule, integrators.cpp:170 */
     int iStep;                                           /* 1-based index of the last completed step (main.cpp:92) */
     /* radiative thermostat state (cuStruct.h:250-255,335-339,384-385) */
@@ -522,12 +523,12 @@ static void put_periodic(orc_sys *s, int i)
        x >= L after the shift (incl. the serial path's surviving x == L) is set to 0 as the
        GPU path does (cuMDfunc.cu:64-69), so the cell index stays in range. */
     double m = s->mass[s->types[i]];
-    if (s->x[i] < 0) { s->x[i] += ((int)(-s->x[i] * s->ra) + 1) * s->la; s->cross[0]++; s->mom[0] += m * (-s->vx[i]); }
-    else if (s->x[i] > s->la) { s->x[i] -= ((int)(s->x[i] * s->ra)) * s->la; s->cross[1]++; s->mom[1] += m * s->vx[i]; }
-    if (s->y[i] < 0) { s->y[i] += ((int)(-s->y[i] * s->rb) + 1) * s->lb; s->cross[2]++; s->mom[2] += m * (-s->vy[i]); }
-    else if (s->y[i] > s->lb) { s->y[i] -= ((int)(s->y[i] * s->rb)) * s->lb; s->cross[3]++; s->mom[3] += m * s->vy[i]; }
-    if (s->z[i] < 0) { s->z[i] += ((int)(-s->z[i] * s->rc_) + 1) * s->lc; s->cross[4]++; s->mom[4] += m * (-s->vz[i]); }
-    else if (s->z[i] > s->lc) { s->z[i] -= ((int)(s->z[i] * s->rc_)) * s->lc; s->cross[5]++; s->mom[5] += m * s->vz[i]; }
+    if (s->x[i] < 0) { s->x[i] += ((int)(-s->x[i] * s->ra) + 1) * s->la; s->cross[0]++; s->specCross[s->types[i] * 6 + 0]++; s->mom[0] += m * (-s->vx[i]); }
+    else if (s->x[i] > s->la) { s->x[i] -= ((int)(s->x[i] * s->ra)) * s->la; s->cross[1]++; s->specCross[s->types[i] * 6 + 1]++; s->mom[1] += m * s->vx[i]; }
+    if (s->y[i] < 0) { s->y[i] += ((int)(-s->y[i] * s->rb) + 1) * s->lb; s->cross[2]++; s->specCross[s->types[i] * 6 + 2]++; s->mom[2] += m * (-s->vy[i]); }
+    else if (s->y[i] > s->lb) { s->y[i] -= ((int)(s->y[i] * s->rb)) * s->lb; s->cross[3]++; s->specCross[s->types[i] * 6 + 3]++; s->mom[3] += m * s->vy[i]; }
+    if (s->z[i] < 0) { s->z[i] += ((int)(-s->z[i] * s->rc_) + 1) * s->lc; s->cross[4]++; s->specCross[s->types[i] * 6 + 4]++; s->mom[4] += m * (-s->vz[i]); }
+    else if (s->z[i] > s->lc) { s->z[i] -= ((int)(s->z[i] * s->rc_)) * s->lc; s->cross[5]++; s->specCross[s->types[i] * 6 + 5]++; s->mom[5] += m * s->vz[i]; }
     if (s->x[i] >= s->la) s->x[i] = 0.0;
     if (s->y[i] >= s->lb) s->y[i] = 0.0;
     if (s->z[i] >= s->lc) s->z[i] = 0.0;
@@ -1077,3 +1078,4 @@ void orc_get_stats(const orc_sys *s, double *out)
     out[16] = s->chit; out[17] = s->conint; out[18] = s->engBond; out[19] = s->engAngle; out[20] = s->engElec1; out[21] = s->engElec2;
 }
 void orc_get_cross(const orc_sys *s, long long *out) { for (int k = 0; k < 6; k++) out[k] = s->cross[k]; }
+void orc_get_species_cross(const orc_sys *s, long long *out) { for (int k = 0; k < 6 * s->nSpec; k++) out[k] = s->specCross[k]; }

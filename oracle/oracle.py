@@ -70,6 +70,7 @@ def lib():
         L.orc_bond_pair.argtypes = [C.c_int, dp, C.c_double, dp]
         L.orc_bond_pair.restype = C.c_double
         L.orc_get_cross.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        L.orc_get_species_cross.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.orc_cells.argtypes = [C.c_void_p, ip]
         L.orc_cells.restype = C.c_int
         L.orc_neig_table.argtypes = [C.c_void_p]
@@ -191,6 +192,12 @@ class Oracle:
         self.L.orc_get_cross(self.h, cr)
         d["cross"] = list(cr)
         return d
+
+    def species_crossings(self):
+        ns = len(self.case["species"])
+        cr = (C.c_longlong * (6 * ns))()
+        self.L.orc_get_species_cross(self.h, cr)
+        return np.array(list(cr), dtype=np.int64).reshape(ns, 6)
 
     def set_vel(self, vx, vy, vz):
         self.L.orc_set_vel(self.h, _dp(_f8(vx)), _dp(_f8(vy)), _dp(_f8(vz)))

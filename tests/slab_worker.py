@@ -76,6 +76,7 @@ def main():
     eng = api.Engine(model, device=dev, slab=slab, **extra)
     eng.step(nsteps)
     st = eng.stats()
+    spec_cross = eng.species_crossings()
     s = eng.state()
     keys = ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz", "U", "radius")
     owned = ~np.isnan(s["x"])
@@ -99,6 +100,7 @@ def main():
                "every_atom_owned_once": bool((cover.numpy() == 1).all()), "max_rel_err_vs_single": max(errs.values()), "errs": errs,
                "energy_rel": {k: abs(st[k] - rst[k]) / (abs(rst[k]) + 1e-300) for k in ("engTot", "engVdW", "engKin", "engCoul", "engTemp", "engBond", "engAngle", "engCoulRec", "engCoulConst") if abs(rst[k]) > 0},
                "cross": [st["negCross"], st["posCross"], rst["negCross"], rst["posCross"]],
+               "species_cross_equal": bool(np.array_equal(spec_cross, ref.species_crossings())),
                "mom_rel": rel_err(st["posMom"] + st["negMom"], rst["posMom"] + rst["negMom"]) if any(rst["posMom"] + rst["negMom"]) else 0.0}
         print("SLAB_RESULT " + json.dumps(out))
     eng.close()

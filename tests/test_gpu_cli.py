@@ -51,6 +51,10 @@ def test_cli_reproduces_oracle(tmp_path):
         assert np.abs(xyz[:, k] - s[c]).max() < 2e-6
     vel = np.loadtxt(os.path.join(d, "velocities.dat"), skiprows=1)
     assert vel.shape == (4000, 5) and np.abs(vel[:, 2] - s["vx"]).max() < 2e-6
+    msd = [ln.split("\t") for ln in open(os.path.join(d, "msd.dat")).read().strip().splitlines()]
+    assert msd[0] == ["time", "step", "Ar_px", "nx", "py", "ny", "pz", "nz"] and len(msd) == 1 + 3          # start_stat cuStat.cu:345-350
+    want = o.species_crossings()[0]               # Xn, Xp, Yn, Yp, Zn, Zp -> the file's px nx py ny pz nz
+    assert [int(v) for v in msd[-1][2:]] == [int(want[k]) for k in (1, 0, 3, 2, 5, 4)] and int(msd[-1][1]) == 60
     tch = np.loadtxt(os.path.join(d, "tchars.dat"), skiprows=1)
     assert np.abs(tch[:, 1] - s["U"]).max() < 2e-6 and np.abs(tch[:, 2] - s["rad"]).max() < 2e-6
 

@@ -302,6 +302,8 @@ def test_wall_crossing_counters_and_field():
     st, sto = e.stats(), o.stats()
     assert sum(sto["cross"]) > 20
     assert [st["negCross"][0], st["posCross"][0], st["negCross"][1], st["posCross"][1], st["negCross"][2], st["posCross"][2]] == sto["cross"]
+    sc = e.species_crossings()                    # per species (the columns of msd.dat): Xn, Xp, Yn, Yp, Zn, Zp
+    assert sc.shape == (2, 6) and np.array_equal(sc, o.species_crossings()) and sc.sum(axis=0).tolist() == sto["cross"] and (sc.sum(axis=1) > 0).all()
     mom = [st["negMom"][0], st["posMom"][0], st["negMom"][1], st["posMom"][1], st["negMom"][2], st["posMom"][2]]
     ref = [sto[k] for k in ("momXn", "momXp", "momYn", "momYp", "momZn", "momZp")]
     assert rel_err(mom, ref) < 1e-11

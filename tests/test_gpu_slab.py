@@ -29,7 +29,7 @@ def test_slabs_match_single_rank(nranks, name, nsteps, port):
     assert out["every_atom_owned_once"] and out["owned_total"] == out["n_atoms"]
     assert out["max_rel_err_vs_single"] < 1e-9, out["errs"]
     assert all(v < 1e-10 for v in out["energy_rel"].values()), out["energy_rel"]
-    assert out["cross"][0] == out["cross"][2] and out["cross"][1] == out["cross"][3]
+    assert out["cross"][0] == out["cross"][2] and out["cross"][1] == out["cross"][3] and out["species_cross_equal"]
     assert out["mom_rel"] < 1e-10
 
 
