@@ -111,6 +111,7 @@ struct StepParams
     // slab decomposition
     double xlo, xhi;              // owned x-range [xlo, xhi)
     int32_t rank, nranks;
+    int32_t fuseKick, padEnd;     // 1: the pair kernel also applies the second half-kick and books the kinetic energy (plain NVE steps)
 };
 
 // reduction slots of the per-block partial buffer (deterministic two-stage sums)

@@ -446,12 +446,17 @@ void Engine::launch_pair()
     if (variant == 0) variant = pair_tile_supported(P_) ? 2 : 1;
     if (variant == 2 && !pair_tile_supported(P_)) variant = 1;
     if (variant == 2)
-        timed("pair_tile", [&] { launch_pair_tile(P_, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_); });
+    {
+        StepParams Q = P_;
+        Q.fuseKick = fuseNow_ ? 1 : 0;
+        timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_); });
+    }
     else
         timed("pair_atom", [&] {
             hipLaunchKernelGGL(k_pair_atom, dim3(div_up(capacity_, kBlock)), dim3(kBlock), 0, stream_, P_, S_, dPots_, cur(), dCounts_, dCellStart_,
                                dCellOfSorted_, dPartials_, maxBlocks_);
         });
+    if (variant != 2) fuseNow_ = false;          // only the tile kernel has the fused epilogue
     pairBlocksUsed_ = (variant == 2) ? pair_tile_grid(P_) : div_up(capacity_, kBlock);
 }
 
@@ -513,7 +518,7 @@ void Engine::collect_and_finalize(unsigned slotMask)
 {
     timed("collect", [&] {
         hipLaunchKernelGGL(k_collect, dim3(PS_COUNT * kCollectParts), dim3(256), 0, stream_, dPartials_, maxBlocks_, div_up(capacity_, kBlock), pairBlocksUsed_,
-                           dStage_, slotMask);
+                           dStage_, slotMask, ekinFromPair_ ? 1 : 0);
     });
     timed("finalize", [&] { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, stream_, P_, dStats_, dStage_, slotMask); });
 }
@@ -537,12 +542,17 @@ void Engine::launch_step_kernels()
 {
     const int gridAtoms = div_up(capacity_, kBlock);
     if (P_.tstat == AZTOT_TSTAT_NOSE) timed("nose_begin", [&] { hipLaunchKernelGGL(k_nose_begin, dim3(1), dim3(64), 0, stream_, P_, dStats_); });
-    sort_and_forces(true);
-    timed("integrate2", [&] {
-        hipLaunchKernelGGL(k_integrate2, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal, dPartials_,
-                           maxBlocks_, dStats_);
-    });
     const bool equil = P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE;     // the step needs the all-atom kinetic energy on the device
+    // plain NVE step with nothing added to the pair forces afterwards: the tile kernel finishes the step itself
+    fuseNow_ = !equil && P_.tstat == AZTOT_TSTAT_NONE && !hasBonded_ && !hasEwald_ && !(opt_.reserved[0] & 128);
+    sort_and_forces(true);
+    ekinFromPair_ = fuseNow_;
+    if (!fuseNow_)
+        timed("integrate2", [&] {
+            hipLaunchKernelGGL(k_integrate2, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal, dPartials_,
+                               maxBlocks_, dStats_);
+        });
+    fuseNow_ = false;
     if (equil)
     {
         timed("reduce_kin", [&] {

@@ -252,6 +252,8 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
     __shared__ double scratch[kBlock / kWave];
     const int begin = cnt->ownedBegin, end = cnt->ownedEnd;
     const int i = begin + blockIdx.x * kBlock + threadIdx.x;
+    if (INTEGRATE && blockIdx.x == 0 && threadIdx.x == 0) st->step += 1;   // the step in flight gets its 1-based number (main.cpp:92);
+                                                                           // read only by the thermostat kernels at the end of the step
     double eField = 0.0, mom[6] = {0, 0, 0, 0, 0, 0}, cross[6] = {0, 0, 0, 0, 0, 0};
     int anyCross = 0, myCell = 0, myLayer = 0;
     if (i < end)
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_totals(int nCell, const int32_t
     if (threadIdx.x == 0) chunkTot[blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_apply(int nCell, const int32_t* __restrict__ cellCount, const int32_t* __restrict__ chunkTot,
+__global__ __launch_bounds__(kBlock) void k_scan_apply(int nCell, int32_t* __restrict__ cellCount, const int32_t* __restrict__ chunkTot,
                                                        int32_t* __restrict__ cellStart, Counts* cnt)
 {
     __shared__ int wt[kBlock / kWave];
@@ -391,7 +393,12 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int nCell, const int32_t*
     const int c0 = blockIdx.x * kScanChunk + tid * 4;
     int v[4], s = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { v[k] = (c0 + k < nCell) ? cellCount[c0 + k] : 0; s += v[k]; }
+    for (int k = 0; k < 4; k++)
+    {   // the histogram is consumed here: leave it cleared for the next step (clear_clist, cuMDfunc.cu:693)
+        v[k] = 0;
+        if (c0 + k < nCell) { v[k] = cellCount[c0 + k]; cellCount[c0 + k] = 0; }
+        s += v[k];
+    }
     int incl = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, kWave); if (lane >= o) incl += n; }
@@ -537,7 +544,6 @@ __global__ __launch_bounds__(kBlock) void k_integrate2(StepParams P, SpecTable S
 {
     __shared__ double scratch[kBlock / kWave];
     const int gid = blockIdx.x * kBlock + threadIdx.x;
-    if (gid == 0) st->step += 1;     // the step in flight gets its 1-based number (main.cpp:92); no other thread of this launch reads it
     for (int c = gid; c < nCell; c += gridDim.x * kBlock) cellCount[c] = 0;
     const int i = cnt->ownedBegin + gid;
     double kin = 0.0;
@@ -598,7 +604,7 @@ __global__ void k_nose_begin(StepParams P, DevStats* st)
 __global__ void k_scale_decision(StepParams P, DevStats* st, const double* __restrict__ ekGlobal)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const long long iStep = st->step;                             // 1-based index of the step in flight (set by k_integrate2)
+    const long long iStep = st->step;                             // 1-based index of the step in flight (set by k_integrate1_bin)
     double ek = ekGlobal[0];
     double k = 1.0;
     bool changed = false;
@@ -722,14 +728,14 @@ __global__ __launch_bounds__(kBlock) void k_post(StepParams P, SpecTable S, Atom
 constexpr int kCollectParts = 16;
 
 __global__ __launch_bounds__(256) void k_collect(double* __restrict__ partials, int maxBlocks, int nBlocksAtoms, int nBlocksPair,
-                                                 double* __restrict__ stage, unsigned slotMask)
+                                                 double* __restrict__ stage, unsigned slotMask, int ekinFromPair)
 {
     __shared__ double scratch[4];
     const int slot = blockIdx.x / kCollectParts, part = blockIdx.x % kCollectParts;
     double v = 0.0;
     if ((slotMask >> slot) & 1u)
     {
-        const int nb = (slot == PS_EVDW || slot == PS_ECOUL || slot == PS_DROPPED) ? nBlocksPair : nBlocksAtoms;
+        const int nb = (slot == PS_EVDW || slot == PS_ECOUL || slot == PS_DROPPED || (slot == PS_EKIN && ekinFromPair)) ? nBlocksPair : nBlocksAtoms;
         const int per = (nb + kCollectParts - 1) / kCollectParts;
         const int b0 = part * per, b1 = min(nb, b0 + per);
         const bool clear = slot_accumulates(slot);

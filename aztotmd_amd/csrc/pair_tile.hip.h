@@ -227,7 +227,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
 
 template <int MODE>   // 0: generic (any potential, Coulomb, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, all LJ, elec none|Fennell ;
                       // 3: as 2 with the real-space term of the Ewald sum
-__global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
+__global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : (MODE == 1 ? 5 : 1)) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks)
 {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
     const int per = (nCellsRun + 7) >> 3;
     const int cr = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     PairAcc acc = {0, 0, 0, 0, 0, 0};
-    double eV = 0.0, eC = 0.0, dropped = 0.0;
+    double eV = 0.0, eC = 0.0, dropped = 0.0, eK = 0.0;
     if (cr < nCellsRun)
     {
         const int cell = firstCell + cr;
@@ -427,9 +427,18 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
             {
                 double q = 0.0;
                 if (MODE != 1) q = S.charge[ti];
-                A.fx[myi] = -q * P.E[0] + acc.fx;          // clear_force integrators.cpp:17-39
-                A.fy[myi] = -q * P.E[1] + acc.fy;
-                A.fz[myi] = -q * P.E[2] + acc.fz;
+                const double fxi = -q * P.E[0] + acc.fx;   // clear_force integrators.cpp:17-39
+                const double fyi = -q * P.E[1] + acc.fy;
+                const double fzi = -q * P.E[2] + acc.fz;
+                A.fx[myi] = fxi; A.fy[myi] = fyi; A.fz[myi] = fzi;
+                if (P.fuseKick)
+                {   // second half-kick + kinetic energy of integrate2 (integrators.cpp:486-531 ; verlet_2stage cuMDfunc.cu:521-600),
+                    // fused here on plain NVE steps: the force is still in registers
+                    const double rM = S.rMhdt[ti], m = S.mass[ti];
+                    const double vx = A.vx[myi] + rM * fxi, vy = A.vy[myi] + rM * fyi, vz = A.vz[myi] + rM * fzi;
+                    A.vx[myi] = vx; A.vy[myi] = vy; A.vz[myi] = vz;
+                    eK += (vx * vx + vy * vy + vz * vz) * m;
+                }
             }
             eV += acc.eV; eC += acc.eC; dropped += acc.dropped;
         }
@@ -440,6 +449,11 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
         put_partial(partials, maxBlocks, PS_EVDW, eV);
         put_partial(partials, maxBlocks, PS_ECOUL, eC);
         if (dropped != 0.0) add_partial(partials, maxBlocks, PS_DROPPED, dropped);
+    }
+    if (P.fuseKick)
+    {
+        eK = wave_sum(eK);
+        if (lane == 0) put_partial(partials, maxBlocks, PS_EKIN, 0.5 * eK);
     }
 }
 

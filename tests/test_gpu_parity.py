@@ -408,6 +408,29 @@ def test_tile_and_atom_kernels_agree_bitwise_on_energy_scale():
         assert rel_err(sa[k], sb[k]) < 1e-13
 
 
+@pytest.mark.parametrize("case_name", ["dense", "aniso", "thin_z"])
+def test_dense_cells_and_odd_shapes(case_name):
+    """~85 atoms per cell (several 64-atom batches per cell, the 320-slot LDS tile flushed many times per cell), an anisotropic
+    grid with charges, and the minimum of three cells along an axis."""
+    if case_name == "dense":        # ~85 atoms per cell
+        case = inputs.lj_case((11, 11, 20), a=1.5, jitter=0.03, seed=3, rc=4.0, cell_list=4.0)
+        case["vdw"] = [(0, 0, 1, 4.0, [0.002, 0.9])]
+    elif case_name == "aniso":
+        case = inputs.lj_case((5, 6, 11), a=5.3, seed=4, rc=7.0, cell_list=7.0, charges=(0.3, -0.3), elec="fenn", r_real=7.0, alpha=0.4)
+    else:
+        case = inputs.lj_case((6, 6, 4), a=5.3, seed=5, rc=7.0, cell_list=7.0)
+    o = oracle.Oracle(case)
+    o.forces(0)
+    so, sto = o.state(), o.stats()
+    for variant in (2, 1):
+        e = engine(case, pair_variant=variant)
+        s, st = e.state(), e.stats()
+        for k in FKEYS:
+            assert rel_err(s[k], so[k]) < 1e-11, (variant, k, rel_err(s[k], so[k]))
+        assert abs(st["engVdW"] - sto["engVdW"]) <= 1e-12 * abs(sto["engVdW"]) + 1e-14
+        assert st["pairs_dropped"] == sto["nDropped"]
+
+
 def test_c2_40k_energy_conservation_and_newton3():
     """BASELINE config 2 (40 000 Ar, rc 8.5): size-independent properties at full size + oracle forces."""
     case = inputs.config("C2")
