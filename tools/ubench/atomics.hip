@@ -1,3 +1,4 @@
+// build: hipcc -O3 --offload-arch=gfx950 atomics.hip -o atomics   (run: tools/ubench/atomics on an MI355X)
 // Micro-benchmark: cost of scattering half-shell pair forces with fp64 global atomics on MI355X.
 // 42^3 cells x 14 atoms; one wave per cell adds to the atoms of its 13 forward neighbour cells + itself (3 components),
 // the access pattern a Newton-3 version of the pair kernel would have.  Variants: device-scope hardware atomics,
