@@ -494,8 +494,13 @@ void Engine::sort_and_forces(bool integrate_first, bool withBonded)
     if (nranks_ > 1) exchange_halo();
     const int nChunks = div_up(P_.nCellLocal, kScanChunk);
     timed("scan_cells", [&] {
-        hipLaunchKernelGGL(k_scan_totals, dim3(nChunks), dim3(kBlock), 0, stream_, P_.nCellLocal, dCellCount_, dChunkTot_);
-        hipLaunchKernelGGL(k_scan_apply, dim3(nChunks), dim3(kBlock), 0, stream_, P_.nCellLocal, dCellCount_, dChunkTot_, dCellStart_, dCounts_);
+        if (P_.nCellLocal <= kScanSingleMax)
+            hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream_, P_.nCellLocal, dCellCount_, dCellStart_, dCounts_);
+        else
+        {
+            hipLaunchKernelGGL(k_scan_totals, dim3(nChunks), dim3(kBlock), 0, stream_, P_.nCellLocal, dCellCount_, dChunkTot_);
+            hipLaunchKernelGGL(k_scan_apply, dim3(nChunks), dim3(kBlock), 0, stream_, P_.nCellLocal, dCellCount_, dChunkTot_, dCellStart_, dCounts_);
+        }
     });
     timed("place", [&] {
         hipLaunchKernelGGL(k_place, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellOf_, dSlotOf_, dCellStart_, cur().id, dTmpId_, dTmpSrc_,

@@ -420,6 +420,41 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int nCell, int32_t* __res
     }
 }
 
+// Single-workgroup variant for small grids (a 40 000-atom box, a rank's slab of a 1 M-atom box): one launch instead of two, no
+// cross-workgroup hand-over - these systems are bound by launch latency, not bandwidth.  The histogram is read and the
+// offsets are written coalesced through an LDS copy; each of the 1024 threads scans a contiguous slice of it.
+constexpr int kScanSingleMax = 16384;
+__global__ __launch_bounds__(1024) void k_scan_single(int nCell, int32_t* __restrict__ cellCount, int32_t* __restrict__ cellStart, Counts* cnt)
+{
+    __shared__ int32_t buf[kScanSingleMax];
+    __shared__ int wt[1024 / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int c = tid; c < nCell; c += 1024) { buf[c] = cellCount[c]; cellCount[c] = 0; }      // consumed: leave it cleared (clear_clist)
+    __syncthreads();
+    const int per = (nCell + 1023) >> 10;
+    const int c0 = min(nCell, tid * per), c1 = min(nCell, c0 + per);
+    int s = 0;
+    for (int c = c0; c < c1; c++) s += buf[c];
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, kWave); if (lane >= o) incl += n; }
+    if (lane == 63) wt[w] = incl;
+    __syncthreads();
+    int run = incl - s;
+    for (int k = 0; k < w; k++) run += wt[k];
+    for (int c = c0; c < c1; c++) { const int v = buf[c]; buf[c] = run; run += v; }
+    __syncthreads();
+    for (int c = tid; c < nCell; c += 1024) cellStart[c] = buf[c];
+    if (tid == 1023)
+    {   // the last thread's running total is the number of resident atoms (slices beyond nCell are empty)
+        cellStart[nCell] = run;
+        cnt->nTotal = run;
+        cnt->srcBegin = cnt->ownedBegin;
+        cnt->srcEnd = cnt->ownedEnd + cnt->nRecv;
+        cnt->nRecv = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5a/K5b: counting-sort placement with a deterministic order inside each cell.
 //   k_place  : provisional slot (atomic arrival order) -> (id, source index) pairs grouped by cell
