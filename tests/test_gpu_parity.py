@@ -431,6 +431,44 @@ def test_dense_cells_and_odd_shapes(case_name):
         assert st["pairs_dropped"] == sto["nDropped"]
 
 
+def _raw_case(pos, box, eps=0.01006, sigma=3.3952):
+    pos = np.asarray(pos, dtype=float)
+    N = len(pos)
+    return {"box": list(box), "dt": 0.001, "nsteps": 0, "species": [(39.9, 0.0)], "vdw": [(0, 0, 1, 8.5, [eps, sigma])],
+            "types": np.zeros(N, dtype=np.int32), "x": pos[:, 0].copy(), "y": pos[:, 1].copy(), "z": pos[:, 2].copy(),
+            "vx": np.zeros(N), "vy": np.zeros(N), "vz": np.zeros(N), "elec_type": 0, "use_clist": 1, "cell_list": 8.5}
+
+
+@pytest.mark.parametrize("name", ["one_atom", "pair_across_the_wall", "everything_in_one_cell", "three_cells_per_axis", "two_cells_per_axis"])
+def test_degenerate_inputs(name):
+    """a single atom, a pair that only interacts through the periodic image, 40 atoms in one cell of an otherwise empty 343-cell box,
+    and boxes of 3 and 2 cells per axis (the latter falls back to the per-atom kernel: a neighbour cell would be reached through
+    two images) - every kernel variant against the oracle, forces and 5 steps."""
+    rng = np.random.default_rng(7)
+    case = {"one_atom": lambda: _raw_case([[1, 2, 3]], [40, 40, 40]),
+            "pair_across_the_wall": lambda: _raw_case([[0.5, 20, 20], [39.0, 20, 20]], [40, 40, 40]),
+            "everything_in_one_cell": lambda: _raw_case(rng.uniform(0.5, 8.0, (40, 3)), [60, 60, 60], eps=1e-4, sigma=1.0),
+            "three_cells_per_axis": lambda: _raw_case(rng.uniform(0, 27, (200, 3)), [27, 27, 27], eps=0.001, sigma=2.0),
+            "two_cells_per_axis": lambda: _raw_case(rng.uniform(0, 18, (100, 3)), [18, 18, 18], eps=0.001, sigma=2.0)}[name]()
+    o = oracle.Oracle(case)
+    o.forces(0)
+    so = o.state()
+    o.step(5)
+    s5 = o.state()
+    scale = max(np.abs(so[k]).max() for k in FKEYS)
+    if name == "pair_across_the_wall":
+        assert scale > 1e-3                      # r = 1.5 A through the wall: strongly repulsive
+    for variant in (1, 2, 0):
+        e = engine(case, pair_variant=variant)
+        s = e.state()
+        for k in FKEYS:
+            assert np.abs(s[k] - so[k]).max() <= 1e-12 * scale, (variant, k)
+        e.step(5)
+        s = e.state()
+        for k in ("x", "vx", "fx"):
+            assert np.abs(s[k] - s5[k]).max() <= 1e-9 * (np.abs(s5[k]).max() + 1e-300), (variant, k)
+
+
 def test_c2_40k_energy_conservation_and_newton3():
     """BASELINE config 2 (40 000 Ar, rc 8.5): size-independent properties at full size + oracle forces."""
     case = inputs.config("C2")
