@@ -25,6 +25,7 @@ void check_hip(hipError_t e, const char* what)
 
 namespace {
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
+constexpr int kFuseKickMaxAtoms = 262144;
 }  // namespace
 
 template <typename F>
@@ -548,8 +549,11 @@ void Engine::launch_step_kernels()
     const int gridAtoms = div_up(capacity_, kBlock);
     if (P_.tstat == AZTOT_TSTAT_NOSE) timed("nose_begin", [&] { hipLaunchKernelGGL(k_nose_begin, dim3(1), dim3(64), 0, stream_, P_, dStats_); });
     const bool equil = P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE;     // the step needs the all-atom kinetic energy on the device
-    // plain NVE step with nothing added to the pair forces afterwards: the tile kernel finishes the step itself
-    fuseNow_ = !equil && P_.tstat == AZTOT_TSTAT_NONE && !hasBonded_ && !hasEwald_ && !(opt_.reserved[0] & 128);
+    // plain NVE step with nothing added to the pair forces afterwards: the tile kernel finishes the step itself.  Only for small
+    // systems / slabs, which are bound by launch latency (one kernel less per step: C2 0.083 -> 0.063 ms).  On 1 M atoms the
+    // 13-lane read-modify-write of the velocities makes L2 write lines back several times (rocprofv3: 221 MB instead of 63 + 76 MB
+    // per step for the two separate kernels) for no gain in time, so large systems keep the streaming k_integrate2.
+    fuseNow_ = !equil && P_.tstat == AZTOT_TSTAT_NONE && !hasBonded_ && !hasEwald_ && capacity_ <= kFuseKickMaxAtoms && !(opt_.reserved[0] & 128);
     sort_and_forces(true);
     ekinFromPair_ = fuseNow_;
     if (!fuseNow_)

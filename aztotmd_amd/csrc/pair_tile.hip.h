@@ -227,7 +227,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
 
 template <int MODE>   // 0: generic (any potential, Coulomb, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, all LJ, elec none|Fennell ;
                       // 3: as 2 with the real-space term of the Ewald sum
-__global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : (MODE == 1 ? 5 : 1)) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
+__global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks)
 {

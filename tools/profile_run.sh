@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence behind bench.py's numbers on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_run.sh [workload]
+# Four separate runs as MI355X_MICROARCH.md prescribes: kernel trace + stats; FETCH_SIZE; WRITE_SIZE; SQ counters.
+set -e
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+W=${1:-C4}
+O=$R/gpurun_out/prof_$W
+rm -rf $O && mkdir -p $O/stats $O/fetch $O/write $O/sq
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --workload $W --steps 50 --warmup 10 --no-cpu-baseline > $O/stats/bench_line.json 2> $O/stats/err.log
+echo "stats done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline --no-profile > $O/fetch/bench_line.json 2> $O/fetch/err.log
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline --no-profile > $O/write/bench_line.json 2> $O/write/err.log
+echo "write done"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- python3 $R/bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline --no-profile > $O/sq/bench_line.json 2> $O/sq/err.log
+echo "sq done"
+python3 $R/tools/pmc_summary.py $O/sq > $O/sq_summary.txt
+find $O -name "*.csv" -size +8M -delete      # the merge-back limit is 64 MiB: keep the summaries, drop bulky traces
+ls -la $O/stats | head
