@@ -86,7 +86,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
 
 EXPORTS = ("aztot_init_md", "aztot_model_create", "aztot_model_set_bonded", "aztot_model_query", "aztot_model_species_name", "aztot_free_md", "aztot_default_options",
            "aztot_init_device", "aztot_free_device", "aztot_step", "aztot_forces", "aztot_get_stats", "aztot_species_crossings", "aztot_md_to_host",
-           "aztot_set_state", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id",
+           "aztot_set_state", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id", "aztot_comm_selftest",
            "aztot_init_device_slab", "aztot_last_error", "aztot_version")
 
 
@@ -141,6 +141,7 @@ def lib():
         L.aztot_reset_kernel_times.argtypes = [C.c_void_p]
         L.aztot_set_profile.argtypes = [C.c_void_p, C.c_int]
         L.aztot_comm_make_id.argtypes = [C.c_void_p]
+        L.aztot_comm_selftest.argtypes = [C.c_int]
         _LIB = L
     return _LIB
 
@@ -392,3 +393,8 @@ def rccl_unique_id():
     buf = C.create_string_buffer(n)
     _check(L.aztot_comm_make_id(buf))
     return buf.raw
+
+
+def rccl_selftest(device=0):
+    """One-rank RCCL communicator: ring exchange with itself + all-reduces (raises AztotError if RCCL is unusable here)."""
+    _check(lib().aztot_comm_selftest(device))

@@ -311,4 +311,9 @@ int aztot_comm_make_id(void* id_bytes)
     return guarded([&] { RcclExchanger::make_id(id_bytes); });
 }
 
+int aztot_comm_selftest(int device)
+{
+    return guarded([&] { RcclExchanger::selftest(device); });
+}
+
 }  // extern "C"

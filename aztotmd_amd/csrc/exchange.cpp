@@ -175,4 +175,44 @@ void RcclExchanger::allreduce_device(double* dev, int n, hipStream_t stream)
     check_nccl(rccl().AllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)comm_, stream), "ncclAllReduce");
 }
 
+void RcclExchanger::selftest(int device)
+{
+    HIP_CHECK(hipSetDevice(device));
+    char id[256];
+    if (id_bytes() > (int)sizeof(id)) throw std::runtime_error("RCCL unique id larger than expected");
+    make_id(id);
+    RcclExchanger x(0, 1, id);
+    hipStream_t st;
+    HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const size_t bytes = 1 << 20;
+    char* d[4];
+    for (auto& p : d) HIP_CHECK(hipMalloc((void**)&p, bytes));
+    std::vector<char> a(bytes), b(bytes), ra(bytes), rb(bytes);
+    for (size_t i = 0; i < bytes; i++) { a[i] = (char)(i * 7 + 1); b[i] = (char)(i * 13 + 5); }
+    HIP_CHECK(hipMemcpyAsync(d[0], a.data(), bytes, hipMemcpyHostToDevice, st));    // leftward message
+    HIP_CHECK(hipMemcpyAsync(d[1], b.data(), bytes, hipMemcpyHostToDevice, st));    // rightward message
+    HIP_CHECK(hipMemsetAsync(d[2], 0, bytes, st));
+    HIP_CHECK(hipMemsetAsync(d[3], 0, bytes, st));
+    x.exchange(0, 0, d[0], d[1], d[2], d[3], bytes, st);                              // fromLeft = d[2], fromRight = d[3]
+    HIP_CHECK(hipMemcpyAsync(ra.data(), d[3], bytes, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(rb.data(), d[2], bytes, hipMemcpyDeviceToHost, st));
+    double h[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+    double* dd;
+    HIP_CHECK(hipMalloc((void**)&dd, sizeof(h)));
+    HIP_CHECK(hipMemcpyAsync(dd, h, sizeof(h), hipMemcpyHostToDevice, st));
+    x.allreduce_device(dd, 8, st);
+    double back[8];
+    HIP_CHECK(hipMemcpyAsync(back, dd, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    double hs[3] = {0.5, -2.0, 1e300};
+    x.allreduce_sum(hs, 3, st);
+    for (auto p : d) (void)hipFree(p);
+    (void)hipFree(dd);
+    (void)hipStreamDestroy(st);
+    // what a rank sends leftward must arrive as its neighbour's "from the right" message, and vice versa
+    if (ra != a || rb != b) throw std::runtime_error("RCCL self-test: ring exchange delivered the wrong payload");
+    for (int k = 0; k < 8; k++) if (back[k] != h[k]) throw std::runtime_error("RCCL self-test: device all-reduce mismatch");
+    if (hs[0] != 0.5 || hs[1] != -2.0 || hs[2] != 1e300) throw std::runtime_error("RCCL self-test: host all-reduce mismatch");
+}
+
 }  // namespace aztot

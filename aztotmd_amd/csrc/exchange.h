@@ -78,6 +78,9 @@ public:
     bool device_side() const override { return true; }
     static int id_bytes();
     static void make_id(void* out);
+    // one-rank communicator on `device`: the ring exchange with itself (both messages, same call order as on N GPUs) and both
+    // all-reduce flavours through the real RCCL library; throws on any mismatch
+    static void selftest(int device);
 
 private:
     void* comm_ = nullptr;

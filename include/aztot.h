@@ -204,6 +204,9 @@ int aztot_set_profile(aztot_md *md, int on);
 /* size of the opaque RCCL unique id; rank 0 creates it, the launcher broadcasts it (e.g. torch.distributed) */
 int aztot_comm_id_bytes(void);
 int aztot_comm_make_id(void *id_bytes);
+/* diagnostic: brings up a ONE-rank RCCL communicator on `device` and runs the slab ring exchange with itself (both messages in
+   the N-GPU call order) plus both all-reduce flavours; AZTOT_OK if RCCL is usable on this node and delivers what was sent */
+int aztot_comm_selftest(int device);
 /* host-staged exchange callback for tests without RCCL (gloo): send `sbytes` to `peer`, receive into rbuf */
 typedef int (*aztot_sendrecv_fn)(void *ctx, int send_peer, const void *sbuf, int64_t sbytes,
                                  int recv_peer, void *rbuf, int64_t rcap, int64_t *rbytes);

@@ -36,3 +36,10 @@ def test_slabs_match_single_rank(nranks, name, nsteps, port):
 def test_slabs_with_per_atom_kernel():
     out = run_ranks(2, "lj", 10, extra={"pair_variant": 1}, port=29615)
     assert out["max_rel_err_vs_single"] < 1e-9
+
+
+def test_rccl_library_selftest():
+    """The slab transport's RCCL calls (dlopen'ed librccl, ncclCommInitRank, one ncclGroup of two sends + two receives in the
+    N-GPU order, ncclAllReduce on the engine stream) on a one-rank communicator: the only way to run them on a one-GPU box."""
+    from aztotmd_amd import api
+    api.rccl_selftest(0)
