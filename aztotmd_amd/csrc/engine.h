@@ -96,6 +96,7 @@ private:
     int pairBlocks_ = 0, pairBlocksUsed_ = 0;
     BondedTables bonded_{};         // all-null when the model has no bonds / angles
     bool hasBonded_ = false;
+    bool thermoTouched_ = false;    // the caller set U / radius on a run whose model does not use them: keep them attached to their atoms
     bool fuseNow_ = false;          // the pair launch in flight also does integrate2's job (plain NVE steps, tile kernel)
     bool ekinFromPair_ = false;     // where the last step left its kinetic-energy partials
     EwaldTables ew_{};              // reciprocal-space Ewald sum ('elec pme')

@@ -509,7 +509,7 @@ void Engine::sort_and_forces(bool integrate_first, bool withBonded)
     });
     timed("rank_gather", [&] {
         hipLaunchKernelGGL(k_rank_gather, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellStart_, dTmpId_, dTmpSrc_, dTmpCell_, cur(), oth(),
-                           dCellOfSorted_, 0, P_, dCounts_, bonded_.idxOfId);
+                           dCellOfSorted_, (P_.tstat == AZTOT_TSTAT_RADI || P_.use_radii || thermoTouched_) ? 2 : 0, P_, dCounts_, bonded_.idxOfId);
     });
     cur_ ^= 1;
     launch_pair();
@@ -735,6 +735,7 @@ void Engine::set_state(const aztot_state& in)
     AtomArrays& A = cur();
     up(in.x, A.x); up(in.y, A.y); up(in.z, A.z); up(in.vx, A.vx); up(in.vy, A.vy); up(in.vz, A.vz);
     up(in.fx, A.fx); up(in.fy, A.fy); up(in.fz, A.fz); up(in.U, A.U); up(in.radius, A.rad);
+    if (in.U || in.radius) thermoTouched_ = true;      // from now on the sort carries the per-atom thermostat state along
 }
 
 }  // namespace aztot

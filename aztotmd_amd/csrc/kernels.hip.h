@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void k_place(const Counts* __restrict__ cnt
 __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict__ cnt, const int32_t* __restrict__ cellStart,
                                                         const int32_t* __restrict__ tmpId, const int32_t* __restrict__ tmpSrc,
                                                         const int32_t* __restrict__ tmpCell, AtomArrays src, AtomArrays dst,
-                                                        int32_t* __restrict__ cellOfSorted, int carryForces, StepParams P, Counts* cntOut,
+                                                        int32_t* __restrict__ cellOfSorted, int carryForces /* bit 0: forces, bit 1: U + radius */, StepParams P, Counts* cntOut,
                                                         int32_t* __restrict__ idxOfId)
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
@@ -502,9 +502,9 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
     const int i = tmpSrc[p];
     dst.x[d] = src.x[i]; dst.y[d] = src.y[i]; dst.z[d] = src.z[i];
     dst.vx[d] = src.vx[i]; dst.vy[d] = src.vy[i]; dst.vz[d] = src.vz[i];
-    dst.U[d] = src.U[i]; dst.rad[d] = src.rad[i];
+    if (carryForces & 2) { dst.U[d] = src.U[i]; dst.rad[d] = src.rad[i]; }     // thermostat state: only when something reads it
     dst.type[d] = src.type[i]; dst.id[d] = myId;
-    if (carryForces) { dst.fx[d] = src.fx[i]; dst.fy[d] = src.fy[i]; dst.fz[d] = src.fz[i]; }
+    if (carryForces & 1) { dst.fx[d] = src.fx[i]; dst.fy[d] = src.fy[i]; dst.fz[d] = src.fz[i]; }
     cellOfSorted[d] = c;
     if (idxOfId) idxOfId[myId] = d;     // bonded terms find their partners through this map (replaces cuSort.cu:199-236)
 }
