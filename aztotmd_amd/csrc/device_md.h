@@ -136,6 +136,8 @@ struct DevStats
     double vscaleBegin;           // Nose-Hoover scale applied at the BEGINNING of the step (integrate1, integrators.cpp:305)
     double ekSim;                 // the reference's sim->engKin as the thermostats see it (value left by the previous integrate2)
     double chit, conint;          // Nose-Hoover friction and conserved-quantity integral (temperature.h:24-25)
+    long long pendingKick;        // 1: the second half-kick of the previous step is still owed (applied by the next k_integrate1_bin,
+                                  //    or by k_integrate2 before anybody can look at the velocities)
     double local[PS_COUNT];       // this rank's per-step sums before the cross-rank reduction
     unsigned long long specCross[kSpecCap * 6];   // per species: crossings of the walls Xn, Xp, Yn, Yp, Zn, Zp (specAcBoxNeg/Pos, cuStruct.h)
 };

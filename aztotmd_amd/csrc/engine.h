@@ -97,6 +97,9 @@ private:
     BondedTables bonded_{};         // all-null when the model has no bonds / angles
     bool hasBonded_ = false;
     bool thermoTouched_ = false;    // the caller set U / radius on a run whose model does not use them: keep them attached to their atoms
+    bool lazyKick_ = false;         // large plain-NVE runs: integrate2 is folded into the next step's integrate1 (flushed by finish_steps)
+    bool kickOwed_ = false;
+    bool fuseEpilogue_ = false;     // small plain-NVE runs: the tile kernel's epilogue applies integrate2
     bool fuseNow_ = false;          // the pair launch in flight also does integrate2's job (plain NVE steps, tile kernel)
     bool ekinFromPair_ = false;     // where the last step left its kinetic-energy partials
     EwaldTables ew_{};              // reciprocal-space Ewald sum ('elec pme')

@@ -173,6 +173,18 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
     allocate();
     upload_bonded();
     upload_ewald();
+    {
+        // who applies the second half-kick on plain NVE steps (nothing is added to the pair forces, nothing rescales velocities)
+        const bool plainNve = !(P_.nEq > 0) && P_.tstat == AZTOT_TSTAT_NONE && !hasBonded_ && !hasEwald_ && !(opt_.reserved[0] & 128);
+        int variant = opt_.pair_variant;
+        if (variant == 0) variant = pair_tile_supported(P_) ? 2 : 1;
+        if (variant == 2 && !pair_tile_supported(P_)) variant = 1;
+        // small systems / slabs are bound by launch latency: the tile kernel's epilogue does it (one kernel less: C2 0.083 -> 0.063 ms).
+        // On 1 M atoms that 13-lane read-modify-write of the velocities makes L2 write lines back several times (rocprofv3: 221 MB
+        // instead of 63 + 76 MB per step) for no gain, so large systems fold it into the next step's streaming k_integrate1_bin.
+        fuseEpilogue_ = plainNve && variant == 2 && capacity_ <= kFuseKickMaxAtoms && !(opt_.reserved[0] & 256);   // debug bit 256: large-system path
+        lazyKick_ = plainNve && !fuseEpilogue_;
+    }
     if (nranks_ > 1 && !xch_)
     {   // options.reserved[1]: loopback measurement mode (see LoopbackExchanger)
         ownedXch_.reset(new LoopbackExchanger((P_.ncxLocal - 2 * P_.hw[0]) * P_.csz[0], P_.L[0], lay_.mig_offset(), lay_.halo_offset(),
@@ -457,7 +469,7 @@ void Engine::launch_pair()
             hipLaunchKernelGGL(k_pair_atom, dim3(div_up(capacity_, kBlock)), dim3(kBlock), 0, stream_, P_, S_, dPots_, cur(), dCounts_, dCellStart_,
                                dCellOfSorted_, dPartials_, maxBlocks_);
         });
-    if (variant != 2) fuseNow_ = false;          // only the tile kernel has the fused epilogue
+    if (variant != 2) fuseNow_ = false;          // only the tile kernel has the fused epilogue (cannot happen: see the constructor)
     pairBlocksUsed_ = (variant == 2) ? pair_tile_grid(P_) : div_up(capacity_, kBlock);
 }
 
@@ -494,13 +506,14 @@ void Engine::sort_and_forces(bool integrate_first, bool withBonded)
     }
     if (nranks_ > 1) exchange_halo();
     const int nChunks = div_up(P_.nCellLocal, kScanChunk);
+    const int setPending = (integrate_first && lazyKick_) ? 1 : 0;
     timed("scan_cells", [&] {
         if (P_.nCellLocal <= kScanSingleMax)
-            hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream_, P_.nCellLocal, dCellCount_, dCellStart_, dCounts_);
+            hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream_, P_.nCellLocal, dCellCount_, dCellStart_, dCounts_, dStats_, setPending);
         else
         {
             hipLaunchKernelGGL(k_scan_totals, dim3(nChunks), dim3(kBlock), 0, stream_, P_.nCellLocal, dCellCount_, dChunkTot_);
-            hipLaunchKernelGGL(k_scan_apply, dim3(nChunks), dim3(kBlock), 0, stream_, P_.nCellLocal, dCellCount_, dChunkTot_, dCellStart_, dCounts_);
+            hipLaunchKernelGGL(k_scan_apply, dim3(nChunks), dim3(kBlock), 0, stream_, P_.nCellLocal, dCellCount_, dChunkTot_, dCellStart_, dCounts_, dStats_, setPending);
         }
     });
     timed("place", [&] {
@@ -549,19 +562,18 @@ void Engine::launch_step_kernels()
     const int gridAtoms = div_up(capacity_, kBlock);
     if (P_.tstat == AZTOT_TSTAT_NOSE) timed("nose_begin", [&] { hipLaunchKernelGGL(k_nose_begin, dim3(1), dim3(64), 0, stream_, P_, dStats_); });
     const bool equil = P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE;     // the step needs the all-atom kinetic energy on the device
-    // plain NVE step with nothing added to the pair forces afterwards: the tile kernel finishes the step itself.  Only for small
-    // systems / slabs, which are bound by launch latency (one kernel less per step: C2 0.083 -> 0.063 ms).  On 1 M atoms the
-    // 13-lane read-modify-write of the velocities makes L2 write lines back several times (rocprofv3: 221 MB instead of 63 + 76 MB
-    // per step for the two separate kernels) for no gain in time, so large systems keep the streaming k_integrate2.
-    fuseNow_ = !equil && P_.tstat == AZTOT_TSTAT_NONE && !hasBonded_ && !hasEwald_ && capacity_ <= kFuseKickMaxAtoms && !(opt_.reserved[0] & 128);
+    // plain NVE steps leave integrate2 to somebody else (decided once, in the constructor): small systems / slabs -> the tile
+    // kernel's epilogue (fuseEpilogue_); large ones -> the next step's k_integrate1_bin (lazyKick_, see finish_steps)
+    fuseNow_ = fuseEpilogue_;
     sort_and_forces(true);
-    ekinFromPair_ = fuseNow_;
-    if (!fuseNow_)
+    const bool fused = fuseNow_;                 // launch_pair drops the request if the tile kernel is not the one running
+    fuseNow_ = false;
+    ekinFromPair_ = fused;
+    if (!fused && !lazyKick_)
         timed("integrate2", [&] {
             hipLaunchKernelGGL(k_integrate2, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal, dPartials_,
                                maxBlocks_, dStats_);
         });
-    fuseNow_ = false;
     if (equil)
     {
         timed("reduce_kin", [&] {
@@ -588,6 +600,14 @@ void Engine::launch_step_kernels()
 // step() call (energies are those of the last step; wall momenta / crossing counts pile up in between)
 void Engine::finish_steps()
 {
+    if (kickOwed_)
+    {   // the deferred second half-kick of the last step + its kinetic energy
+        timed("integrate2", [&] {
+            hipLaunchKernelGGL(k_integrate2, dim3(div_up(capacity_, kBlock)), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal,
+                               dPartials_, maxBlocks_, dStats_);
+        });
+        kickOwed_ = false;
+    }
     unsigned mask = (1u << PS_COUNT) - 1u;
     if (P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE) mask &= ~(1u << PS_EKIN);   // k_reduce_kin / k_scale_decision own engKin then
     if (!(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_RADI)) mask &= ~(1u << PS_ETEMP);
@@ -619,6 +639,7 @@ void Engine::step(int nsteps)
         while (nsteps - done >= 2) { HIP_CHECK(hipGraphLaunch(graphExec_[g], stream_)); done += 2; }
     }
     for (; done < nsteps; done++) launch_step_kernels();
+    kickOwed_ = lazyKick_;          // set here, not in launch_step_kernels: a replayed graph does not pass through the host code
     finish_steps();
     sync();
     check_overflow();

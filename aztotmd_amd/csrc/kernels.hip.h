@@ -252,6 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
     __shared__ double scratch[kBlock / kWave];
     const int begin = cnt->ownedBegin, end = cnt->ownedEnd;
     const int i = begin + blockIdx.x * kBlock + threadIdx.x;
+    const bool pendingKick = INTEGRATE && st->pendingKick != 0;   // written only by kernels that run between two launches of this one
     if (INTEGRATE && blockIdx.x == 0 && threadIdx.x == 0) st->step += 1;   // the step in flight gets its 1-based number (main.cpp:92);
                                                                            // read only by the thermostat kernels at the end of the step
     double eField = 0.0, mom[6] = {0, 0, 0, 0, 0, 0}, cross[6] = {0, 0, 0, 0, 0, 0};
@@ -265,9 +266,11 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
             const double rM = S.rMhdt[t], m = S.mass[t];
             double vx = A.vx[i], vy = A.vy[i], vz = A.vz[i];
             if (P.tstat == 1) { const double sc = st->vscaleBegin; vx *= sc; vy *= sc; vz *= sc; }   // tstat_nose at integrators.cpp:305-306
-            vx += rM * A.fx[i];
-            vy += rM * A.fy[i];
-            vz += rM * A.fz[i];
+            const double fxo = A.fx[i], fyo = A.fy[i], fzo = A.fz[i];
+            if (pendingKick) { vx += rM * fxo; vy += rM * fyo; vz += rM * fzo; }   // integrate2 of the previous step, deferred (same f, same order)
+            vx += rM * fxo;
+            vy += rM * fyo;
+            vz += rM * fzo;
             if (!S.frozen[t]) { x += vx * P.dt; y += vy * P.dt; z += vz * P.dt; }
             int c;
             c = wrap_coord(x, P.L[0], P.invL[0]);
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_totals(int nCell, const int32_t
 }
 
 __global__ __launch_bounds__(kBlock) void k_scan_apply(int nCell, int32_t* __restrict__ cellCount, const int32_t* __restrict__ chunkTot,
-                                                       int32_t* __restrict__ cellStart, Counts* cnt)
+                                                       int32_t* __restrict__ cellStart, Counts* cnt, DevStats* st, int setPending)
 {
     __shared__ int wt[kBlock / kWave];
     __shared__ int chunkBase;
@@ -417,6 +420,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int nCell, int32_t* __res
         cnt->srcBegin = cnt->ownedBegin;
         cnt->srcEnd = cnt->ownedEnd + cnt->nRecv;
         cnt->nRecv = 0;
+        st->pendingKick = setPending;     // whether this step leaves its second half-kick to the next k_integrate1_bin
     }
 }
 
@@ -424,7 +428,8 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int nCell, int32_t* __res
 // cross-workgroup hand-over - these systems are bound by launch latency, not bandwidth.  The histogram is read and the
 // offsets are written coalesced through an LDS copy; each of the 1024 threads scans a contiguous slice of it.
 constexpr int kScanSingleMax = 16384;
-__global__ __launch_bounds__(1024) void k_scan_single(int nCell, int32_t* __restrict__ cellCount, int32_t* __restrict__ cellStart, Counts* cnt)
+__global__ __launch_bounds__(1024) void k_scan_single(int nCell, int32_t* __restrict__ cellCount, int32_t* __restrict__ cellStart, Counts* cnt,
+                                                     DevStats* st, int setPending)
 {
     __shared__ int32_t buf[kScanSingleMax];
     __shared__ int wt[1024 / kWave];
@@ -452,6 +457,7 @@ __global__ __launch_bounds__(1024) void k_scan_single(int nCell, int32_t* __rest
         cnt->srcBegin = cnt->ownedBegin;
         cnt->srcEnd = cnt->ownedEnd + cnt->nRecv;
         cnt->nRecv = 0;
+        st->pendingKick = setPending;     // whether this step leaves its second half-kick to the next k_integrate1_bin
     }
 }
 
@@ -579,6 +585,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate2(StepParams P, SpecTable S
 {
     __shared__ double scratch[kBlock / kWave];
     const int gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid == 0) st->pendingKick = 0;       // this launch pays the kick
     for (int c = gid; c < nCell; c += gridDim.x * kBlock) cellCount[c] = 0;
     const int i = cnt->ownedBegin + gid;
     double kin = 0.0;

@@ -400,6 +400,32 @@ def test_bitwise_reproducible_and_graph_equals_eager():
         assert np.array_equal(runs[0][k], runs[1][k]) and np.array_equal(runs[0][k], runs[2][k])
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_second_half_kick_ownership(variant):
+    """On plain NVE steps integrate2's work is done by the tile kernel's epilogue (small systems), by the next step's
+    k_integrate1_bin (large systems; debug bit 256 forces that path here) or by k_integrate2 itself (debug bit 128): the three must
+    agree bit for bit in x, v, f and in the energies, across graph replays (10 + 20 steps), odd step counts and repeated calls."""
+    case = inputs.lj_case((6, 6, 6), a=5.3, seed=17, rc=7.0, cell_list=7.0, vel_T=150.0)
+    ref = None
+    for dbg in (128, 256, 0):
+        e = engine(case, debug=dbg, pair_variant=variant)
+        kin = []
+        for n in (10, 20, 7, 1):
+            e.step(n)
+            kin.append(e.stats()["engKin"])
+        s = e.state()
+        if ref is None:
+            ref = (kin, s)
+            continue
+        for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+            assert np.array_equal(s[k], ref[1][k]), (dbg, k)
+        assert np.allclose(kin, ref[0], rtol=1e-13, atol=0), (dbg, kin, ref[0])       # summation order of the partials differs
+    o = oracle.Oracle(case)
+    o.forces(0)
+    o.step(38)
+    assert abs(kin[-1] - o.stats()["engKin"]) < 1e-11 * kin[-1]
+
+
 def test_tile_and_atom_kernels_agree_bitwise_on_energy_scale():
     case = inputs.config("F3")
     a, b = engine(case, pair_variant=1), engine(case, pair_variant=2)
