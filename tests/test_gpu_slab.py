@@ -33,6 +33,14 @@ def test_slabs_match_single_rank(nranks, name, nsteps, port):
     assert out["mom_rel"] < 1e-10
 
 
+def test_slabs_with_deferred_half_kick():
+    """debug bit 256: the large-system path (second half-kick applied by the next step's k_integrate1_bin, which in slab mode also
+    packs the migrants and the halo from the freshly kicked velocities)."""
+    out = run_ranks(2, "lj", 25, extra={"debug": 256}, port=29620)
+    assert out["every_atom_owned_once"] and out["max_rel_err_vs_single"] < 1e-9, out["errs"]
+    assert all(v < 1e-10 for v in out["energy_rel"].values()), out["energy_rel"]
+
+
 def test_slabs_with_per_atom_kernel():
     out = run_ranks(2, "lj", 10, extra={"pair_variant": 1}, port=29615)
     assert out["max_rel_err_vs_single"] < 1e-9
