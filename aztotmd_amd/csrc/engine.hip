@@ -213,12 +213,31 @@ void Engine::allocate()
     const int N = model_.nAt;
     if (nranks_ > 1)
     {
-        // owned share + two ghost slabs + migration slack, with head-room for density fluctuations
-        const double frac = (double)P_.ncxLocal / P_.nc[0];
-        capacity_ = (int)std::min<double>((double)N, std::ceil(N * frac * 1.5) + 4096);
-        const double layerAtoms = (double)N / P_.nc[0];
-        lay_.haloCap = (int)std::min<double>((double)N, std::ceil(layerAtoms * P_.hw[0] * 1.6) + 1024);
-        lay_.migCap = (int)std::min<double>((double)N, std::ceil(layerAtoms * 0.25) + 1024);
+        // Capacities from the ACTUAL initial population of the x-layers (every rank holds the whole model, so all ranks arrive at
+        // the same message size): the fixed-size message is what travels every step, so padding costs link time.
+        //   halo      the fullest run of hw consecutive layers + 25 %
+        //   migrants  3 % of the fullest layer (an atom moves << one cell per step: v dt / edge ~ 1e-3) + 1024
+        //   arrays    this rank's window (owned + ghost layers) + 25 %
+        const int ncx = P_.nc[0], hw = P_.hw[0];
+        std::vector<long long> hist(ncx, 0);
+        for (int i = 0; i < N; i++)
+        {
+            int gx = (int)std::floor(model_.x[i] * P_.icsz[0]);
+            gx %= ncx; if (gx < 0) gx += ncx;
+            hist[gx]++;
+        }
+        long long maxLayer = 0, maxRun = 0, window = 0;
+        for (int g = 0; g < ncx; g++)
+        {
+            maxLayer = std::max(maxLayer, hist[g]);
+            long long run = 0;
+            for (int k = 0; k < hw; k++) run += hist[(g + k) % ncx];
+            maxRun = std::max(maxRun, run);
+        }
+        for (int l = 0; l < P_.ncxLocal; l++) window += hist[(((P_.cx0 + l) % ncx) + ncx) % ncx];
+        capacity_ = (int)std::min<double>((double)N, std::ceil(window * 1.25) + 4096);
+        lay_.haloCap = (int)std::min<double>((double)N, std::ceil(maxRun * 1.25) + 1024);
+        lay_.migCap = (int)std::min<double>((double)N, std::ceil(maxLayer * 0.03) + 1024);
     }
     else capacity_ = N;
     nCellAlloc_ = P_.nCellLocal;
