@@ -457,6 +457,45 @@ def test_dense_cells_and_odd_shapes(case_name):
         assert st["pairs_dropped"] == sto["nDropped"]
 
 
+@pytest.mark.skipif(not oracle.ref_available(), reason="oracle/_ref/ref_driver did not travel to this machine")
+@pytest.mark.parametrize("name", ["lj_nose", "buck", "bmhs", "fennel_field", "direct", "ewald", "bonded"])
+def test_hip_path_against_the_reference_binary(name):
+    """No oracle in between: the HIP hot path against the reference's OWN compiled serial code (oracle/_ref/ref_driver: box.cpp,
+    vdw.cpp, elec.cpp, cell_list.cpp, integrators.cpp, temperature.cpp, bonds.cpp, angles.cpp built where they lie) on the same
+    inputs - forces at step 0 to 1e-11, trajectory after 30 steps to 1e-9 (the north star's tolerance), energies to 1e-10."""
+    if name == "lj_nose":
+        case = inputs.lj_case((5, 5, 5), a=5.26, seed=21, rc=6.5, cell_list=6.5, T=140.0, vel_T=100.0)
+        case.update(tstat_type=1, tau=0.08, nEq=12, freqEq=4)
+    elif name == "buck":
+        case = mixed_case("buck", seed=5)
+    elif name == "bmhs":
+        case = mixed_case("bmhs", seed=6)
+    elif name == "fennel_field":
+        case = mixed_case("lnjs+fenn+field", seed=7)
+        case.update(Uy=0.0, Uz=0.0)       # the serial clear_force knows only dU/dx (integrators.cpp:17-39); y, z are the GPU path's
+    elif name == "direct":
+        case = mixed_case("lnjs+dir", seed=8)
+    elif name == "ewald":
+        case = ewald_case(ewald_k=(5, 6, 7))
+    else:
+        case = inputs.molecular_case((9, 9, 9), seed=31, charges=(-0.2, 0.1), elec="fenn")
+    case = dict(case)
+    case.update(nsteps=30, dump=[0, 30])
+    ref = oracle.run_ref(case)
+    e = engine(case)
+    d0, d30 = ref["dumps"][0], ref["dumps"][30]
+    s = e.state()
+    for k in FKEYS:
+        assert rel_err(s[k], d0[k]) < 1e-11, (name, k)
+    e.step(30)
+    s, st = e.state(), e.stats()
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(s[k], d30[k]) < 1e-9, (name, k, rel_err(s[k], d30[k]))
+    for a, b in (("engVdW", "engVdW"), ("engCoul", "engElec3"), ("engKin", "engKin"), ("engTot", "engTot"), ("engBond", "engBond"),
+                 ("engAngle", "engAngle"), ("engCoulRec", "engElec2"), ("engCoulConst", "engElec1")):
+        assert abs(st[a] - d30[b]) <= 1e-10 * abs(d30[b]) + 1e-12, (name, a, st[a], d30[b])
+
+
 def _raw_case(pos, box, eps=0.01006, sigma=3.3952):
     pos = np.asarray(pos, dtype=float)
     N = len(pos)
