@@ -52,6 +52,16 @@ __device__ __forceinline__ double fast_rcp(double x)
     return y;
 }
 
+// 1/sqrt(x): v_rsq_f64 refined by two Newton steps (y += y/2 (1 - x y^2)); 9 instructions for what gives r = x y, 1/r = y and
+// 1/r^2 = y y, instead of the reciprocal above plus ocml's range-scaled sqrt.  x is a squared distance: normal, positive.
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+    y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+    return y;
+}
+
 // number of set bits of a 64-bit ballot below this lane: two v_mbcnt instructions
 __device__ __forceinline__ int lanes_below(unsigned long long mask)
 {
@@ -80,26 +90,43 @@ __device__ __forceinline__ int ld_i32(const int32_t* __restrict__ base, int j)
 // erfc(x) = ex * p(t), t = 3u - 2, u = 1/(1 + x/2), p = our own degree-16 fit of erfcx (tools/fit_erfcx.py; max relative error
 // 8e-15 against scipy on [0, 4]).  24 instructions instead of ocml's 140-instruction erfc plus a second exp; the host selects
 // this kernel only when alpha * rc <= 4.  tests/test_gpu_parity.py checks the result against the oracle's libm erfc.
+// Coefficients live in constant memory so that they reach the polynomial chains through scalar registers: as 64-bit literals
+// every one of them costs a v_mov_b64 per use inside the pair loop (57 of the 199 VALU instructions of the Coulomb body).
+__constant__ double kCoulCoef[32] = {
+    // [0..16] erfcx fit, highest degree first
+    3.11400876136111478e-10, -6.43174152465694238e-10, -2.62442874509777347e-09, 1.54097035921259372e-08, -2.06548182619811564e-08,
+    -1.28511981631567555e-07, 7.28044471457273614e-07, -4.70993577663208179e-07, -9.92741548786899564e-06, 3.46017753152724625e-05,
+    1.00396629412378288e-04, -8.61280658253346654e-04, -1.60202363270953250e-03, 2.25095126335783415e-02, 1.42427001998883335e-01,
+    4.09818022175859609e-01, 4.27583576155806666e-01,
+    // [17..19] log2(e), ln2 high part (32 trailing zero bits), ln2 low part
+    1.44269504088896338700e+00, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+    // [20..30] 1/12! ... 1/2!  (exp Taylor series on |r| <= ln2/2: truncation 1.7e-16 relative)
+    2.08767569878680989792e-09, 2.50521083854417187751e-08, 2.75573192239858906526e-07, 2.75573192239858906526e-06,
+    2.48015873015873015873e-05, 1.98412698412698412698e-04, 1.38888888888888888889e-03, 8.33333333333333333333e-03,
+    4.16666666666666666667e-02, 1.66666666666666666667e-01, 5.00000000000000000000e-01,
+    0.0};
+
+// exp(y) for -700 < y <= 0: n = rint(y log2 e), r = y - n ln2 (two-part), Taylor to r^12, scaled by 2^n.  ~21 instructions.
+__device__ __forceinline__ double exp_nonpos(double y)
+{
+    y = fmax(y, -700.0);                           // masked-out pairs arrive with y = -1e299: keep the reduction finite (result ~1e-304)
+    const double n = rint(y * kCoulCoef[17]);
+    double r = fma(-n, kCoulCoef[18], y);
+    r = fma(-n, kCoulCoef[19], r);
+    double p = kCoulCoef[20];
+#pragma unroll
+    for (int k = 21; k <= 30; k++) p = fma(p, r, kCoulCoef[k]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 __device__ __forceinline__ double erfc_given_exp(double x, double ex)
 {
     const double t = fma(3.0, fast_rcp(fma(0.5, x, 1.0)), -2.0);
-    double p = 3.11400876136111478e-10;
-    p = fma(p, t, -6.43174152465694238e-10);
-    p = fma(p, t, -2.62442874509777347e-09);
-    p = fma(p, t, 1.54097035921259372e-08);
-    p = fma(p, t, -2.06548182619811564e-08);
-    p = fma(p, t, -1.28511981631567555e-07);
-    p = fma(p, t, 7.28044471457273614e-07);
-    p = fma(p, t, -4.70993577663208179e-07);
-    p = fma(p, t, -9.92741548786899564e-06);
-    p = fma(p, t, 3.46017753152724625e-05);
-    p = fma(p, t, 1.00396629412378288e-04);
-    p = fma(p, t, -8.61280658253346654e-04);
-    p = fma(p, t, -1.60202363270953250e-03);
-    p = fma(p, t, 2.25095126335783415e-02);
-    p = fma(p, t, 1.42427001998883335e-01);
-    p = fma(p, t, 4.09818022175859609e-01);
-    p = fma(p, t, 4.27583576155806666e-01);
+    double p = kCoulCoef[0];
+#pragma unroll
+    for (int k = 1; k <= 16; k++) p = fma(p, t, kCoulCoef[k]);
     return ex * p;
 }
 
@@ -107,7 +134,7 @@ constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-
 
 template <int MODE, int LG>
 __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots, const DevPot& lj,
-                                            const double* tx, const double* ty, const double* tz, const int32_t* ttyp, const double* trad,
+                                            const double* tx, const double* ty, const double* tz, const uint8_t* ttyp, const double* trad,
                                             const double* pairTab, int T, int slice, double xi, double yi, double zi, int ti, double radi,
                                             PairAcc& acc)
 {
@@ -186,7 +213,9 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 const double* pp = pairTab + (ti * P.nSpec + ttyp[k]) * 5;
                 const bool pairOk = live & (r2 > 0.0) & (r2 <= P.r2Max);
                 const double r2s = pairOk ? r2 : 1e300;
-                const double r2i = fast_rcp(r2s);
+                const bool coul = (MODE == 3) || (P.elec_type == 3);               // wave-uniform
+                const double ir = coul ? fast_rsqrt(r2s) : 0.0;
+                const double r2i = coul ? ir * ir : fast_rcp(r2s);
                 const bool vdwOk = r2s <= pp[3];
                 const double sr2 = vdwOk ? pp[1] * r2i : 0.0;
                 const double sr6 = sr2 * sr2 * sr2;
@@ -195,9 +224,9 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 if (MODE == 2 && P.elec_type == 3)
                 {
                     const double kqq = pairOk ? pp[4] : 0.0;
-                    const double r = sqrt(r2s), ir = r * r2i;
+                    const double r = r2s * ir;
                     const double ar = P.alpha * r;
-                    const double ex = exp(-ar * ar);
+                    const double ex = exp_nonpos(-ar * ar);
                     const double erfcar = erfc_given_exp(ar, ex);
                     acc.eC = fma(0.5 * kqq, erfcar * ir - P.el_scale + P.el_scale2 * (r - P.rReal), acc.eC);
                     f = fma(kqq * ir, (erfcar * r2i + P.daipi2 * ex * ir) - P.el_scale2, f);
@@ -205,9 +234,9 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 else if (MODE == 3)
                 {   // real-space term of the Ewald sum: coul_iter elec.cpp:344-369 (real_ewald cuElec.cu:94-113)
                     const double kqq = pairOk ? pp[4] : 0.0;
-                    const double r = sqrt(r2s), ir = r * r2i;
+                    const double r = r2s * ir;
                     const double ar = P.alpha * r;
-                    const double ex = exp(-ar * ar);
+                    const double ex = exp_nonpos(-ar * ar);
                     const double erfcar = erfc_given_exp(ar, ex);
                     acc.eC = fma(0.5 * kqq, erfcar * ir, acc.eC);
                     f = fma(kqq * ir * r2i, fma(P.daipi2 * r, ex, erfcar), f);
@@ -232,7 +261,7 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                                                      double* __restrict__ partials, int maxBlocks)
 {
     __shared__ double tx[kTileLds], ty[kTileLds], tz[kTileLds];
-    __shared__ int32_t ttyp[MODE != 1 ? kTileLds : 1];
+    __shared__ uint8_t ttyp[MODE != 1 ? kTileLds : 1];               // species ids (< 16)
     __shared__ double trad[MODE == 0 ? kTileLds : 1];
     __shared__ double pairTab[MODE >= 2 ? kLjSpecMax * kLjSpecMax * 5 : 1];
     __shared__ int32_t entJ[kWave], entN[kWave], entC[kWave];       // staging table: first atom, count (<= 64), image-shift code
@@ -293,7 +322,12 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
             auto process = [&]() {
                 // far-away, FINITE dummies behind the last candidate: the passes need no bounds checks, and dead lanes have a
                 // harmless candidate to chew on (uninitialised LDS could hold NaN patterns: 0 * NaN would poison a force)
-                if (lane < kTilePad) { tx[T + lane] = -1e30; ty[T + lane] = 0.0; tz[T + lane] = 0.0; }
+                if (lane < kTilePad)
+                {
+                    tx[T + lane] = -1e30; ty[T + lane] = 0.0; tz[T + lane] = 0.0;
+                    if (MODE != 1) ttyp[T + lane] = 0;          // a valid species: the parameter table is indexed with it
+                    if (MODE == 0) trad[T + lane] = 0.0;
+                }
                 __builtin_amdgcn_wave_barrier();
                 if (!(P.pad0 & 1))
                 {
@@ -403,7 +437,7 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                                 {
                                     const int pp = T + lanes_below(mask);
                                     tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
-                                    if (MODE != 1) ttyp[pp] = gtyp[u];
+                                    if (MODE != 1) ttyp[pp] = (uint8_t)gtyp[u];
                                     if (MODE == 0) trad[pp] = grad[u];
                                 }
                                 T += __popcll(mask);
