@@ -102,6 +102,73 @@ __device__ __forceinline__ void min_image(double& d, double L, double half)
 }
 
 // ------------------------------------------------------------------------------------------------
+// fast fp64 building blocks of the Coulomb terms (full double accuracy, a fraction of ocml's instruction count)
+// ------------------------------------------------------------------------------------------------
+// 1/x: v_rcp_f64 (about 2^-24 relative) refined by two Newton steps -> error within ~1 ulp; 5 instructions instead
+// of the 11 of the IEEE division sequence.  x is a squared distance inside the cut-off: normal, positive.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+
+// 1/sqrt(x): v_rsq_f64 refined by two Newton steps (y += y/2 (1 - x y^2)); 9 instructions for what gives r = x y, 1/r = y and
+// 1/r^2 = y y, instead of the reciprocal above plus ocml's range-scaled sqrt.  x is a squared distance: normal, positive.
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+    y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+    return y;
+}
+
+// erfc(x) for 0 <= x <= 4 given ex = exp(-x*x), which the caller needs anyway (Fennell / Ewald force term):
+// erfc(x) = ex * p(t), t = 3u - 2, u = 1/(1 + x/2), p = our own degree-16 fit of erfcx (tools/fit_erfcx.py; max relative error
+// 8e-15 against scipy on [0, 4]).  24 instructions instead of ocml's 140-instruction erfc plus a second exp; the host selects
+// this kernel only when alpha * rc <= 4.  tests/test_gpu_parity.py checks the result against the oracle's libm erfc.
+// Coefficients live in constant memory so that they reach the polynomial chains through scalar registers: as 64-bit literals
+// every one of them costs a v_mov_b64 per use inside the pair loop (57 of the 199 VALU instructions of the Coulomb body).
+__constant__ double kCoulCoef[32] = {
+    // [0..16] erfcx fit, highest degree first
+    3.11400876136111478e-10, -6.43174152465694238e-10, -2.62442874509777347e-09, 1.54097035921259372e-08, -2.06548182619811564e-08,
+    -1.28511981631567555e-07, 7.28044471457273614e-07, -4.70993577663208179e-07, -9.92741548786899564e-06, 3.46017753152724625e-05,
+    1.00396629412378288e-04, -8.61280658253346654e-04, -1.60202363270953250e-03, 2.25095126335783415e-02, 1.42427001998883335e-01,
+    4.09818022175859609e-01, 4.27583576155806666e-01,
+    // [17..19] log2(e), ln2 high part (32 trailing zero bits), ln2 low part
+    1.44269504088896338700e+00, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+    // [20..30] 1/12! ... 1/2!  (exp Taylor series on |r| <= ln2/2: truncation 1.7e-16 relative)
+    2.08767569878680989792e-09, 2.50521083854417187751e-08, 2.75573192239858906526e-07, 2.75573192239858906526e-06,
+    2.48015873015873015873e-05, 1.98412698412698412698e-04, 1.38888888888888888889e-03, 8.33333333333333333333e-03,
+    4.16666666666666666667e-02, 1.66666666666666666667e-01, 5.00000000000000000000e-01,
+    0.0};
+
+// exp(y) for -700 < y <= 0: n = rint(y log2 e), r = y - n ln2 (two-part), Taylor to r^12, scaled by 2^n.  ~21 instructions.
+__device__ __forceinline__ double exp_nonpos(double y)
+{
+    y = fmax(y, -700.0);                           // masked-out pairs arrive with y = -1e299: keep the reduction finite (result ~1e-304)
+    const double n = rint(y * kCoulCoef[17]);
+    double r = fma(-n, kCoulCoef[18], y);
+    r = fma(-n, kCoulCoef[19], r);
+    double p = kCoulCoef[20];
+#pragma unroll
+    for (int k = 21; k <= 30; k++) p = fma(p, r, kCoulCoef[k]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+__device__ __forceinline__ double erfc_given_exp(double x, double ex)
+{
+    const double t = fma(3.0, fast_rcp(fma(0.5, x, 1.0)), -2.0);
+    double p = kCoulCoef[0];
+#pragma unroll
+    for (int k = 1; k <= 16; k++) p = fma(p, t, kCoulCoef[k]);
+    return ex * p;
+}
+
+// ------------------------------------------------------------------------------------------------
 // pair functions: f = -(1/r) dU/dr, energy added to eV / eC.  Operation order follows the serial
 // reference (vdw.cpp:16-157, elec.cpp:415-444); elin/einv/surk follow cuVdW.cu:162-257 in fp64.
 // ------------------------------------------------------------------------------------------------
@@ -178,19 +245,22 @@ __device__ __forceinline__ double coul_force(const StepParams& P, double qq, dou
         eng += kqq / r;
         return kqq / r / r2;
     }
-    else if (P.elec_type == 3)
+    // erfc / exp: the shared-exp erfcx fit when the whole range alpha r <= alpha rReal <= 4 is inside its domain (wave-uniform
+    // choice), libm otherwise
+    const bool fit = P.alpha * P.rReal <= 4.0;
+    const double ar = P.alpha * r;
+    const double ex = fit ? exp_nonpos(-ar * ar) : exp(-ar * ar);
+    const double erfcar = fit ? erfc_given_exp(ar, ex) : erfc(ar);
+    if (P.elec_type == 3)
     {   // fennel elec.cpp:430-444
         double ir = 1.0 / r;
-        double ar = P.alpha * r;
-        double erfcar = erfc(ar);
         eng += kqq * (erfcar * ir - P.el_scale + P.el_scale2 * (r - P.rReal));
-        return kqq * ir * ((erfcar / r2 + P.daipi2 * exp(-ar * ar) * ir) - P.el_scale2);
+        return kqq * ir * ((erfcar / r2 + P.daipi2 * ex * ir) - P.el_scale2);
     }
     else
     {   // coul_iter elec.cpp:344-369 (real-space Ewald term)
-        double ar = P.alpha * r, erfcar = erfc(ar);
         eng += kqq * erfcar / r;
-        return kqq / r / r2 * (erfcar + 2 * ar / P.sqrtpi * exp(-ar * ar));
+        return kqq / r / r2 * (erfcar + 2 * ar / P.sqrtpi * ex);
     }
 }
 
