@@ -66,6 +66,7 @@ def cpu_baseline(case, steps):
                 raise RuntimeError("ref_driver failed: " + r.stderr[-500:])
             summ = json.loads(r.stdout.strip().splitlines()[-1])
         wall = summ["wall_s"]
+        energies = {"engVdW": summ.get("engVdW"), "engTot": summ.get("engTot")}
         kind = "reference"
     else:
         o = oracle.Oracle(case)
@@ -73,12 +74,13 @@ def cpu_baseline(case, steps):
         t0 = time.perf_counter()
         o.step(steps)
         wall = time.perf_counter() - t0
+        energies = None          # started from the initial forces, unlike the reference sample below: no same-run comparison
         kind = "port"
     nsday = steps * dt * 1e-3 / wall * 86400.0
     return {"value": nsday, "unit": "ns/day", "cores": 1, "kind": kind,
             "sample": "%d steps of the same %d-atom workload, linked-cell serial path, 1 thread; %.2f s wall; %.3f Matom-steps/s"
                       % (steps, n, wall, n * steps / wall / 1e6),
-            "host_cpu": _cpu_model(), "host_cores": os.cpu_count()}
+            "host_cpu": _cpu_model(), "host_cores": os.cpu_count(), "_energies": energies}
 
 
 def _cpu_model():
@@ -237,6 +239,18 @@ def main():
             steps_cpu = min(steps_cpu, 200)
             try:
                 out["cpu_baseline"] = cpu_baseline(case, steps_cpu)
+                ref_e = out["cpu_baseline"].pop("_energies", None)
+                if ref_e and ref_e.get("engTot") is not None:
+                    # same inputs, same number of steps, same start (F = 0 as the reference sample): the HIP path's energies next to
+                    # the CPU reference's, in this very run (force-level parity is the test suite's job)
+                    chk = api.Engine(model, device=local_rank, initial_forces=0, pair_variant=a.pair_variant, cell_size=a.cell_size)
+                    chk.step(steps_cpu)
+                    cs = chk.stats()
+                    chk.close()
+                    out["cpu_baseline"]["same_run_parity"] = {
+                        "steps": steps_cpu, "engVdW_gpu": cs["engVdW"], "engVdW_cpu": ref_e["engVdW"],
+                        "engVdW_rel_diff": abs(cs["engVdW"] - ref_e["engVdW"]) / abs(ref_e["engVdW"]),
+                        "engTot_rel_diff": abs(cs["engTot"] - ref_e["engTot"]) / abs(ref_e["engTot"])}
             except Exception as ex:   # noqa: BLE001 - the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "ns/day", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
         sys.stdout.flush()
