@@ -111,7 +111,8 @@ struct StepParams
     // slab decomposition
     double xlo, xhi;              // owned x-range [xlo, xhi)
     int32_t rank, nranks;
-    int32_t fuseKick, padEnd;     // 1: the pair kernel also applies the second half-kick and books the kinetic energy (plain NVE steps)
+    int32_t fuseKick;             // 1: the pair kernel also applies the second half-kick and books the kinetic energy (plain NVE steps)
+    int32_t vdwFamily;            // pad1 == 2: the one potential type all defined species pairs share (1 lnjs, 2 buck, 3 p746, 4 bmhs)
 };
 
 // reduction slots of the per-block partial buffer (deterministic two-stage sums)

@@ -154,12 +154,20 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
     P_.use_radii = 0;
     for (const auto& p : m.pairpots) if (p.type && p.use_radii) P_.use_radii = 1;
     P_.single_lj = (m.nSpec() == 1 && m.pairpots[0].type == AZTOT_VDW_LJ && m.elec_type == AZTOT_ELEC_NONE) ? 1 : 0;
-    {   // kernel specialisation 2: few species, every pair potential Lennard-Jones (or absent), electrostatics none or Fennell
-        bool allLj = m.nSpec() <= 4 && !P_.single_lj &&
-                     (m.elec_type == AZTOT_ELEC_NONE || m.elec_type == AZTOT_ELEC_FENNEL || m.elec_type == AZTOT_ELEC_EWALD);
-        for (const auto& p : m.pairpots) if (p.type != 0 && p.type != AZTOT_VDW_LJ) allLj = false;
-        if ((m.elec_type == AZTOT_ELEC_FENNEL || m.elec_type == AZTOT_ELEC_EWALD) && m.alpha * m.rReal > 4.0) allLj = false;   // range of erfc_given_exp
-        P_.pad1 = allLj ? 2 : 0;
+    {   // kernel specialisation 2/3: few species, ONE potential family among lnjs / buck / p746 / bmhs for every defined pair, no
+        // radius-dependent potential, electrostatics none / direct / Fennell / Ewald inside the domain of the erfcx fit
+        int family = 0;
+        bool uniform = m.nSpec() <= 4 && !P_.single_lj;
+        for (const auto& p : m.pairpots)
+        {
+            if (p.type == 0) continue;
+            if (p.use_radii || p.type < AZTOT_VDW_LJ || p.type > AZTOT_VDW_BHM) uniform = false;
+            if (family == 0) family = p.type; else if (family != p.type) uniform = false;
+        }
+        if (family == 0) family = AZTOT_VDW_LJ;          // charges only: any family does, nothing is inside a VdW cut-off
+        if ((m.elec_type == AZTOT_ELEC_FENNEL || m.elec_type == AZTOT_ELEC_EWALD) && m.alpha * m.rReal > 4.0) uniform = false;
+        P_.pad1 = uniform ? 2 : 0;
+        P_.vdwFamily = uniform ? family : 0;
     }
     std::memset(&S_, 0, sizeof(S_));
     for (int i = 0; i < m.nSpec(); i++)

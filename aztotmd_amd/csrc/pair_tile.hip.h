@@ -66,9 +66,10 @@ __device__ __forceinline__ int ld_i32(const int32_t* __restrict__ base, int j)
 // rocprof shows the kernel VALU-issue bound (VALU busy ~85 %), so this is all about instructions per wave: constant
 // LDS offsets (NS is a template parameter), no bounds clamps (far-away dummies pad the tile), Newton-refined
 // v_rcp_f64, branch-free potential.
+constexpr int kPairTabStride = 8;   // {p0..p4, r2cut, kqq, aux} per ordered species pair
 constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-Jones / charge-product table in LDS
 
-template <int MODE, int LG>
+template <int MODE, int VDW, int LG>
 __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots, const DevPot& lj,
                                             const double* tx, const double* ty, const double* tz, const uint8_t* ttyp, const double* trad,
                                             const double* pairTab, int T, int slice, double xi, double yi, double zi, int ti, double radi,
@@ -144,23 +145,54 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 acc.fx = fma(fm, dx, acc.fx); acc.fy = fma(fm, dy, acc.fy); acc.fz = fma(fm, dz, acc.fz);
             }
             else if (MODE >= 2)
-            {   // every species pair is Lennard-Jones (fer_lj vdw.cpp:16-26), electrostatics none or Fennell/DSF (fennel
-                // elec.cpp:430-444); parameters per species pair come from a small LDS table: {p0, p1, p2, r2cut, kqq}
-                const double* pp = pairTab + (ti * P.nSpec + ttyp[k]) * 5;
+            {   // one potential family for every species pair (VDW: 1 lnjs, 2 buck, 3 p746, 4 bmhs - fer_* of vdw.cpp:16-157), electrostatics
+                // none, direct, Fennell/DSF (fennel elec.cpp:430-444) or the real-space Ewald term; parameters per species pair come from a
+                // small LDS table {p0..p4, r2cut, kqq, aux}.  Branch-free: a pair outside its potential's cut-off is multiplied away.
+                const double* pp = pairTab + (ti * P.nSpec + ttyp[k]) * kPairTabStride;
                 const bool pairOk = live & (r2 > 0.0) & (r2 <= P.r2Max);
                 const double r2s = pairOk ? r2 : 1e300;
-                const bool coul = (MODE == 3) || (P.elec_type == 3);               // wave-uniform
-                const double ir = coul ? fast_rsqrt(r2s) : 0.0;
-                const double r2i = coul ? ir * ir : fast_rcp(r2s);
-                const bool vdwOk = r2s <= pp[3];
-                const double sr2 = vdwOk ? pp[1] * r2i : 0.0;
-                const double sr6 = sr2 * sr2 * sr2;
-                acc.eV = fma(0.5 * pp[0], sr6 * (sr6 - 1.0), acc.eV);
-                double f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
+                const bool coul = (MODE == 3) || (P.elec_type != 0);               // wave-uniform
+                const bool needR = coul || VDW != 1;
+                const double ir = needR ? fast_rsqrt(r2s) : 0.0;
+                const double r2i = needR ? ir * ir : fast_rcp(r2s);
+                const double r = r2s * ir;
+                const bool vdwOk = r2s <= pp[5];
+                double f;
+                if (VDW == 1)
+                {   // fer_lj vdw.cpp:16-26: p0 = 4 eps, p1 = sigma^2, p2 = 24 eps
+                    const double sr2 = vdwOk ? pp[1] * r2i : 0.0;
+                    const double sr6 = sr2 * sr2 * sr2;
+                    acc.eV = fma(0.5 * pp[0], sr6 * (sr6 - 1.0), acc.eV);
+                    f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
+                }
+                else
+                {
+                    const double w = vdwOk ? 1.0 : 0.0;
+                    const double r4i = r2i * r2i, r6i = r4i * r2i;
+                    double e;
+                    if (VDW == 2)
+                    {   // fer_buckingham vdw.cpp:60-70: A exp(-r/rho) - C/r^6 ; aux = 1/rho
+                        const double ex = pp[0] * exp_nonpos(-r * pp[7]);
+                        e = ex - pp[2] * r6i;
+                        f = ex * ir * pp[7] - 6.0 * pp[2] * r4i * r4i;
+                    }
+                    else if (VDW == 3)
+                    {   // fer_746 vdw.cpp:144-157: p0/r^7 - p1/r^4 - p2/r^6
+                        e = r4i * (pp[0] * r2i * ir - pp[1] - pp[2] * r2i);
+                        f = r6i * (7.0 * pp[0] * r2i * ir - 4.0 * pp[1] - 6.0 * pp[2] * r2i);
+                    }
+                    else
+                    {   // fer_bhm vdw.cpp:102-112: A exp(B (sigma - r)) - C/r^6 - D/r^8
+                        const double ex = pp[0] * exp_nonpos(pp[1] * (pp[2] - r));
+                        e = ex - pp[3] * r6i - pp[4] * r4i * r4i;
+                        f = pp[1] * ex * ir - 6.0 * pp[3] * r4i * r4i - 8.0 * pp[4] * r4i * r4i * r2i;
+                    }
+                    acc.eV = fma(0.5 * w, e, acc.eV);
+                    f *= w;
+                }
                 if (MODE == 2 && P.elec_type == 3)
                 {
-                    const double kqq = pairOk ? pp[4] : 0.0;
-                    const double r = r2s * ir;
+                    const double kqq = pairOk ? pp[6] : 0.0;
                     const double ar = P.alpha * r;
                     const double ex = exp_nonpos(-ar * ar);
                     const double erfcar = erfc_given_exp(ar, ex);
@@ -169,13 +201,18 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 }
                 else if (MODE == 3)
                 {   // real-space term of the Ewald sum: coul_iter elec.cpp:344-369 (real_ewald cuElec.cu:94-113)
-                    const double kqq = pairOk ? pp[4] : 0.0;
-                    const double r = r2s * ir;
+                    const double kqq = pairOk ? pp[6] : 0.0;
                     const double ar = P.alpha * r;
                     const double ex = exp_nonpos(-ar * ar);
                     const double erfcar = erfc_given_exp(ar, ex);
                     acc.eC = fma(0.5 * kqq, erfcar * ir, acc.eC);
                     f = fma(kqq * ir * r2i, fma(P.daipi2 * r, ex, erfcar), f);
+                }
+                else if (MODE == 2 && P.elec_type == 1)
+                {   // direct_coul elec.cpp:415-428
+                    const double kqq = pairOk ? pp[6] : 0.0;
+                    acc.eC = fma(0.5 * kqq, ir, acc.eC);
+                    f = fma(kqq * ir, r2i, f);
                 }
                 const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
                 nDropHalf += __popcll(__ballot(tooBig));
@@ -190,7 +227,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
     if (MODE != 0 && threadIdx.x == 0) acc.dropped += 0.5 * (double)nDropHalf;
 }
 
-template <int MODE>   // 0: generic (any potential, Coulomb, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, all LJ, elec none|Fennell ;
+template <int MODE, int VDW>   // 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;
                       // 3: as 2 with the real-space term of the Ewald sum
 __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
@@ -199,7 +236,7 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
     __shared__ double tx[kTileLds], ty[kTileLds], tz[kTileLds];
     __shared__ uint8_t ttyp[MODE != 1 ? kTileLds : 1];               // species ids (< 16)
     __shared__ double trad[MODE == 0 ? kTileLds : 1];
-    __shared__ double pairTab[MODE >= 2 ? kLjSpecMax * kLjSpecMax * 5 : 1];
+    __shared__ double pairTab[MODE >= 2 ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
     __shared__ int32_t entJ[kWave], entN[kWave], entC[kWave];       // staging table: first atom, count (<= 64), image-shift code
 
     const int lane = threadIdx.x;
@@ -225,9 +262,11 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
             {
                 const DevPot v = pots[lane];
                 const int a = lane / P.nSpec, b = lane - a * P.nSpec;
-                pairTab[lane * 5 + 0] = v.p0; pairTab[lane * 5 + 1] = v.p1; pairTab[lane * 5 + 2] = v.p2;
-                pairTab[lane * 5 + 3] = v.type ? v.r2cut : -1.0;
-                pairTab[lane * 5 + 4] = (S.charged[a] && S.charged[b]) ? S.charge[a] * S.charge[b] * P.fcoul : 0.0;
+                double* q = pairTab + lane * kPairTabStride;
+                q[0] = v.p0; q[1] = v.p1; q[2] = v.p2; q[3] = v.p3; q[4] = v.p4;
+                q[5] = v.type ? v.r2cut : -1.0;                                   // no potential for this pair: never inside the cut-off
+                q[6] = (S.charged[a] && S.charged[b]) ? S.charge[a] * S.charge[b] * P.fcoul : 0.0;
+                q[7] = (VDW == 2 && v.type) ? 1.0 / v.p1 : 0.0;
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -267,9 +306,9 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                 __builtin_amdgcn_wave_barrier();
                 if (!(P.pad0 & 1))
                 {
-                    if (lg == 4) tile_passes<MODE, 4>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
-                    else if (lg == 5) tile_passes<MODE, 5>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
-                    else tile_passes<MODE, 6>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
+                    if (lg == 4) tile_passes<MODE, VDW, 4>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
+                    else if (lg == 5) tile_passes<MODE, VDW, 5>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
+                    else tile_passes<MODE, VDW, 6>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
                 }
                 __builtin_amdgcn_wave_barrier();
                 T = 0;
@@ -427,21 +466,34 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
     }
 }
 
-inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts*, const int32_t* cellStart,
-                             double* partials, int maxBlocks, hipStream_t stream)
+template <int MODE, int VDW>
+inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const int32_t* cellStart, double* partials,
+                                int maxBlocks, hipStream_t stream)
 {
     const int nRun = pair_tile_cells(P);
     const int plane = P.nc[1] * P.nc[2];
     const int first = (P.nranks > 1) ? P.hw[0] * plane : 0;
-    const int grid = pair_tile_grid(P);
-    if (P.single_lj)
-        hipLaunchKernelGGL(k_pair_tile<1>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
-    else if (P.pad1 == 2 && P.elec_type == 2)
-        hipLaunchKernelGGL(k_pair_tile<3>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
-    else if (P.pad1 == 2)
-        hipLaunchKernelGGL(k_pair_tile<2>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
-    else
-        hipLaunchKernelGGL(k_pair_tile<0>, dim3(grid), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
+    hipLaunchKernelGGL((k_pair_tile<MODE, VDW>), dim3(pair_tile_grid(P)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
+}
+
+// P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs), <= 4 species, no radii,
+// electrostatics none / direct / Fennell / Ewald with alpha rReal <= 4 (Engine::Engine decides)
+inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts*, const int32_t* cellStart,
+                             double* partials, int maxBlocks, hipStream_t stream)
+{
+    if (P.single_lj) { launch_pair_tile_as<1, 1>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return; }
+    if (P.pad1 == 2)
+    {
+        const bool ew = P.elec_type == 2;
+        switch (P.vdwFamily)
+        {
+        case 1: if (ew) launch_pair_tile_as<3, 1>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 1>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
+        case 2: if (ew) launch_pair_tile_as<3, 2>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 2>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
+        case 3: if (ew) launch_pair_tile_as<3, 3>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 3>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
+        case 4: if (ew) launch_pair_tile_as<3, 4>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 4>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
+        }
+    }
+    launch_pair_tile_as<0, 0>(P, S, pots, A, cellStart, partials, maxBlocks, stream);
 }
 
 }  // namespace aztot

@@ -247,6 +247,10 @@ def config(name):
         return lj_case((63, 63, 63), seed=20240502, charges=(0.2, -0.2), elec="fenn")
     if name == "C4":      # 1 000 188 atoms, pure LJ
         return lj_case((63, 63, 63), seed=20240502)
+    if name == "B3":      # 1 000 188 ions, Born-Mayer-Huggins + Fennell: the generic (any-potential) pair path at full size
+        c = lj_case((63, 63, 63), seed=20240505, charges=(0.2, -0.2), elec="fenn")
+        c["vdw"] = [(0, 0, 4, 8.5, [0.25, 3.1, 3.3, 60.0, 80.0]), (0, 1, 4, 8.5, [0.25, 3.1, 3.2, 50.0, 60.0]), (1, 1, 4, 8.5, [0.25, 3.1, 3.4, 70.0, 90.0])]
+        return c
     if name == "E2":      # 40 000 ions, LJ + full Ewald sum ('elec pme 8.5 0.35 12 12 14'; "next" row f4)
         c = lj_case((20, 20, 25), seed=20240504, charges=(0.2, -0.2), elec="fenn", r_real=8.5, alpha=0.35)
         c.update(elec_type=2, ewald_k=(12, 12, 14))
