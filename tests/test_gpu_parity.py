@@ -13,7 +13,7 @@ import pytest
 
 from aztotmd_amd import api, inputs
 from oracle import oracle
-from util import mixed_case, rel_err
+from util import family_with_coulomb, mixed_case, rel_err
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -48,6 +48,28 @@ def test_initial_forces_match_oracle(name, variant):
 @pytest.mark.parametrize("pot", ["buck", "bmhs", "p746", "elin", "einv", "lnjs+dir", "lnjs+fenn+field"])
 def test_potential_families(pot, variant):
     check_forces(mixed_case(pot), pair_variant=variant)
+
+
+@pytest.mark.parametrize("elec", ["dir", "fenn", "ewald"])
+@pytest.mark.parametrize("family", ["lnjs", "buck", "p746", "bmhs"])
+def test_family_kernels_with_coulomb(family, elec):
+    """the specialised tile kernels (one potential family x none/direct/Fennell/Ewald, branch-free bodies, erfcx fit, own exp and
+    rsqrt) against the oracle's libm arithmetic, and bit-for-bit energy agreement is NOT expected: 1e-11 forces, 1e-12 energies."""
+    case = family_with_coulomb(family, elec)
+    o = oracle.Oracle(case)
+    o.forces(0)
+    so, sto = o.state(), o.stats()
+    for variant in (2, 1):
+        e = engine(case, pair_variant=variant)
+        s, st = e.state(), e.stats()
+        for k in FKEYS:
+            assert rel_err(s[k], so[k]) < 1e-11, (variant, k, rel_err(s[k], so[k]))
+        assert abs(st["engVdW"] - sto["engVdW"]) <= 1e-12 * abs(sto["engVdW"]) + 1e-14
+        assert abs(st["engCoul"] - sto["engElec3"]) <= 1e-12 * abs(sto["engElec3"]) + 1e-14
+    e.step(20)
+    o.step(20)
+    for k in ("x", "vx", "fx"):
+        assert rel_err(e.state()[k], o.state()[k]) < 1e-9, k
 
 
 @pytest.mark.parametrize("variant", [1, 2])

@@ -37,3 +37,15 @@ def mixed_case(pot, n=5, a=5.6, seed=99, rc=7.0, vel_T=90.0):
             base.update(elec_type=3, rReal=rc, alpha=0.35, Ux=0.02, Uy=-0.01, Uz=0.005)
     base.update(species=sp, vdw=vdw, names=names)
     return base
+
+
+def family_with_coulomb(family, elec, **kw):
+    """One potential family (buck / bmhs / p746 / lnjs) for every species pair + charges with the given electrostatics
+    ('dir', 'fenn', 'ewald'): the combinations the specialised tile kernels (MODE 2 / 3 x family) cover."""
+    base = mixed_case(family if family != "lnjs" else "lnjs+dir", **kw)
+    base["species"] = [(39.9, 0.3), (20.2, -0.3)]
+    rc = 7.0
+    base.update(elec_type={"dir": 1, "ewald": 2, "fenn": 3}[elec], rReal=rc, alpha=0.0 if elec == "dir" else 0.4)
+    if elec == "ewald":
+        base["ewald_k"] = (5, 5, 5)
+    return base
