@@ -77,3 +77,23 @@ def test_cli_bonded_columns(tmp_path):
         st = o.stats()
         for col, key in ((2, "engTot"), (3, "engKin"), (4, "engVdW"), (7, "engBond"), (8, "engAngle")):
             assert abs(float(row[col]) - st[key]) <= 2e-6 + 1e-9 * abs(st[key]), (row[1], key, row[col], st[key])
+
+
+def test_cli_ewald_columns(tmp_path):
+    """'elec pme' through the program: engCoul1 (real space) and engCoul2 (reciprocal space) columns of stat.dat
+    (cudaMD::engCoul1/2, cuStat.cu:244-245) against the oracle's engElec3 / engElec2."""
+    case = inputs.lj_case((5, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5, charges=(0.4, -0.4), elec="fenn", r_real=6.5, alpha=0.45)
+    case.update(elec_type=2, ewald_k=(6, 6, 6), nsteps=20)
+    d = str(tmp_path / "pme")
+    inputs.write_input_files(case, d, stat=10)
+    exe = os.path.join(ROOT, "aztotmd_amd", "aztotmd")
+    r = subprocess.run([exe, d, "--out", d], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = [ln.split("\t") for ln in open(os.path.join(d, "stat.dat")).read().strip().splitlines()]
+    assert rows[0][5:7] == ["engCoul1", "engCoul2"] and len(rows) == 4
+    o = oracle.Oracle(case)
+    for row in rows[2:]:
+        o.step(10)
+        st = o.stats()
+        for col, key in ((2, "engTot"), (4, "engVdW"), (5, "engElec3"), (6, "engElec2")):
+            assert abs(float(row[col]) - st[key]) <= 2e-6 + 1e-9 * abs(st[key]), (row[1], key, row[col], st[key])
