@@ -247,6 +247,19 @@ def config(name):
         return lj_case((63, 63, 63), seed=20240502, charges=(0.2, -0.2), elec="fenn")
     if name == "C4":      # 1 000 188 atoms, pure LJ
         return lj_case((63, 63, 63), seed=20240502)
+    if name == "C1":      # synthetic twin of 'case study 1': 40 000 Ar gas atoms in a 1141.5 A box, LJ rc 4 A, cell_list 85 A, radiative thermostat
+        rng = np.random.Generator(np.random.PCG64(20240506))
+        N, L = 40000, 1141.5
+        g = 35                                              # 35^3 = 42 875 lattice sites, 32.6 A apart, +-12 A jitter: a gas without overlaps
+        site = rng.permutation(g ** 3)[:N]
+        pos = np.stack([site // (g * g), (site // g) % g, site % g], axis=1) * (L / g) + L / (2 * g) + rng.uniform(-12.0, 12.0, size=(N, 3))
+        pos = np.round(np.mod(pos, L), 6)
+        pos[pos >= L] = 0.0
+        return {"box": [L, L, L], "dt": 0.001, "nsteps": 0, "species": [(AR_MASS, 0.0)], "names": ["Ar"],
+                "vdw": [(0, 0, VDW_TYPES["lnjs"], 4.0, [AR_EPS, AR_SIGMA])], "types": np.zeros(N, dtype=np.int32),
+                "x": pos[:, 0].copy(), "y": pos[:, 1].copy(), "z": pos[:, 2].copy(), "vx": np.zeros(N), "vy": np.zeros(N), "vz": np.zeros(N),
+                "elec_type": 0, "rReal": 0.0, "alpha": 0.0, "T": 298.0, "tstat_type": 2, "nEq": 0, "freqEq": 1, "use_clist": 1,
+                "cell_list": 85.0, "center_box": 0, "init_forces": 1, "radii": None, "seed": 12345}
     if name == "B3":      # 1 000 188 ions, Born-Mayer-Huggins + Fennell: the generic (any-potential) pair path at full size
         c = lj_case((63, 63, 63), seed=20240505, charges=(0.2, -0.2), elec="fenn")
         c["vdw"] = [(0, 0, 4, 8.5, [0.25, 3.1, 3.3, 60.0, 80.0]), (0, 1, 4, 8.5, [0.25, 3.1, 3.2, 50.0, 60.0]), (1, 1, 4, 8.5, [0.25, 3.1, 3.4, 70.0, 90.0])]
