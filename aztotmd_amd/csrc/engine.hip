@@ -225,7 +225,7 @@ void Engine::allocate()
         // the same message size): the fixed-size message is what travels every step, so padding costs link time.
         //   halo      the fullest run of hw consecutive layers + 25 %
         //   migrants  3 % of the fullest layer (an atom moves << one cell per step: v dt / edge ~ 1e-3) + 1024
-        //   arrays    this rank's window (owned + ghost layers) + 25 %
+        //   arrays    this rank's window (owned + ghost layers) + one ghost run + 25 %
         const int ncx = P_.nc[0], hw = P_.hw[0];
         std::vector<long long> hist(ncx, 0);
         for (int i = 0; i < N; i++)
@@ -243,7 +243,10 @@ void Engine::allocate()
             maxRun = std::max(maxRun, run);
         }
         for (int l = 0; l < P_.ncxLocal; l++) window += hist[(((P_.cx0 + l) % ncx) + ncx) % ncx];
-        capacity_ = (int)std::min<double>((double)N, std::ceil(window * 1.25) + 4096);
+        // arrays: the received atoms are appended behind the owned range while last step's left ghosts still sit in front of it, so
+        // the footprint is window + one more ghost run - NOT bounded by N on a short ring (2 ranks x 3-4 layers), where the window
+        // alone already covers most of the box
+        capacity_ = (int)(std::ceil((window + maxRun) * 1.25) + 4096);
         lay_.haloCap = (int)std::min<double>((double)N, std::ceil(maxRun * 1.25) + 1024);
         lay_.migCap = (int)std::min<double>((double)N, std::ceil(maxLayer * 0.03) + 1024);
     }

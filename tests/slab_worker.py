@@ -61,6 +61,9 @@ def main():
     elif name == "ewald":    # structure factors are summed over the ranks every step
         case = inputs.lj_case((14, 5, 5), a=5.26, seed=8, rc=6.5, cell_list=6.5, charges=(0.4, -0.4), elec="fenn", r_real=6.5, alpha=0.45, vel_T=300.0)
         case.update(elec_type=2, ewald_k=(8, 5, 5))
+    elif name.startswith("rand"):   # seeded random system (tests/util.py random_case), box stretched along x to fit the ranks
+        from util import random_case
+        case = random_case(int(name[4:]), x_cells=2 * world + 2)
     elif name == "hot":
         case = inputs.lj_case((14, 5, 5), a=5.4, seed=3, rc=7.0, cell_list=7.0, vel_T=4000.0)
     else:

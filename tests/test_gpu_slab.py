@@ -33,6 +33,16 @@ def test_slabs_match_single_rank(nranks, name, nsteps, port):
     assert out["mom_rel"] < 1e-10
 
 
+@pytest.mark.parametrize("seed,nranks", [(3, 2), (6, 3), (9, 2), (13, 4)])
+def test_slabs_on_random_systems(seed, nranks):
+    """seeded random systems (potential mixes, Ewald / Fennell / direct, several species, external field) cut into slabs"""
+    out = run_ranks(nranks, "rand%d" % seed, 20, port=29630 + seed)
+    assert out["every_atom_owned_once"] and out["owned_total"] == out["n_atoms"]
+    assert out["max_rel_err_vs_single"] < 1e-9, out["errs"]
+    assert all(v < 1e-9 for v in out["energy_rel"].values()), out["energy_rel"]
+    assert out["species_cross_equal"]
+
+
 def test_slabs_with_deferred_half_kick():
     """debug bit 256: the large-system path (second half-kick applied by the next step's k_integrate1_bin, which in slab mode also
     packs the migrants and the halo from the freshly kicked velocities)."""

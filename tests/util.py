@@ -49,3 +49,56 @@ def family_with_coulomb(family, elec, **kw):
     if elec == "ewald":
         base["ewald_k"] = (5, 5, 5)
     return base
+
+
+def random_case(seed, x_cells=0):
+    """A random small system: box shape, density, cut-off, cell edge (below and above the cut-off), 1-3 species, potential family mix,
+    electrostatics, external field - whatever the input surface allows for the pair path."""
+    rng = np.random.default_rng(1000 + seed)
+    box = rng.uniform(16.0, 34.0, size=3)
+    rc = float(rng.uniform(4.0, min(7.5, 0.49 * box.min())))
+    N = int(rng.integers(150, 700))
+    if x_cells:                                                  # slab tests: a box long enough along x for that many cut-off lengths
+        box[0] = rc * x_cells * float(rng.uniform(1.02, 1.3))
+        N = int(N * box[0] / 25.0)
+    ns = int(rng.integers(1, 4))
+    # points with a minimum separation (rejection on a jittered grid) so that no pair sits deep inside the repulsive wall
+    g = np.ceil(N ** (1 / 3)).astype(int) + 1
+    sites = rng.permutation(g ** 3)[:N]
+    pos = (np.stack([sites // (g * g), (sites // g) % g, sites % g], axis=1) + 0.5 + rng.uniform(-0.2, 0.2, size=(N, 3))) * (box / g)
+    pos = np.mod(pos, box)
+    types = rng.integers(0, ns, size=N).astype(np.int32)
+    fam = ["lnjs", "buck", "bmhs", "p746", "mixed", "elin"][int(rng.integers(0, 6))]
+    d0 = float((box.prod() / N) ** (1 / 3))                     # typical neighbour distance: keeps the potentials in a sane range
+    vdw = []
+    for a_ in range(ns):
+        for b_ in range(a_, ns):
+            rcp = rc * float(rng.uniform(0.7, 1.0))
+            kind = fam if fam != "mixed" else ["lnjs", "buck", "bmhs"][int(rng.integers(0, 3))]
+            if kind == "lnjs":
+                vdw.append((a_, b_, 1, rcp, [float(rng.uniform(0.005, 0.02)), 0.8 * d0]))
+            elif kind == "buck":
+                vdw.append((a_, b_, 2, rcp, [float(rng.uniform(500, 2000)), 0.09 * d0, float(rng.uniform(5, 40))]))
+            elif kind == "bmhs":
+                vdw.append((a_, b_, 4, rcp, [0.25, float(rng.uniform(2.5, 3.5)), 0.8 * d0, float(rng.uniform(5, 40)), float(rng.uniform(5, 40))]))
+            elif kind == "p746":
+                vdw.append((a_, b_, 3, rcp, [float(rng.uniform(500, 3000)) * (d0 / 3.0) ** 7, 1.0, float(rng.uniform(5, 30))]))
+            else:
+                vdw.append((a_, b_, 5, rcp, [float(rng.uniform(300, 900)), 0.12 * d0, float(rng.uniform(0.001, 0.004))]))
+            if rng.random() < 0.15 and len(vdw) > 1:
+                vdw.pop()                                        # some species pairs have no potential at all
+    elec = ["none", "dir", "fenn", "ewald"][int(rng.integers(0, 4))]
+    charges = rng.uniform(-0.4, 0.4, size=ns) if elec != "none" else np.zeros(ns)
+    if elec != "none" and ns > 1 and rng.random() < 0.3:
+        charges[0] = 0.0                                        # a neutral species among charged ones
+    case = {"box": [float(v) for v in box], "dt": 0.0005, "nsteps": 0, "species": [(float(rng.uniform(10, 60)), float(q)) for q in charges],
+            "vdw": vdw, "types": types, "x": pos[:, 0].copy(), "y": pos[:, 1].copy(), "z": pos[:, 2].copy(),
+            "vx": rng.normal(0, 1.0, N), "vy": rng.normal(0, 1.0, N), "vz": rng.normal(0, 1.0, N),
+            "elec_type": {"none": 0, "dir": 1, "ewald": 2, "fenn": 3}[elec], "rReal": rc if elec != "none" else 0.0,
+            "alpha": float(rng.uniform(0.3, 0.55)) if elec in ("fenn", "ewald") else 0.0, "use_clist": 1,
+            "cell_list": rc * float(rng.choice([0.45, 0.7, 1.0, 1.3]) if not x_cells else rng.choice([1.0, 1.15])), "Ux": float(rng.choice([0.0, 0.01])), "Uy": 0.0, "Uz": float(rng.choice([0.0, -0.02]))}
+    if elec == "ewald":
+        case["ewald_k"] = tuple(int(v) for v in rng.integers(3, 8, size=3))
+    if elec != "none" and not np.any(charges != 0.0):
+        case["elec_type"] = 0
+    return case
