@@ -13,7 +13,7 @@ import pytest
 
 from aztotmd_amd import api, inputs
 from oracle import oracle
-from util import family_with_coulomb, mixed_case, random_case, rel_err
+from util import add_random_dynamics, family_with_coulomb, mixed_case, random_case, rel_err
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -539,6 +539,28 @@ def test_randomised_configurations(seed):
     s, s2 = e.state(), o.state()
     for k in ("x", "vx", "fx"):
         assert rel_err(s[k], s2[k]) < 1e-8, (seed, k, rel_err(s[k], s2[k]))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_randomised_dynamics(seed):
+    """the random systems again, now with a thermostat (Nose-Hoover, radiative) and/or an equilibration schedule and with bonds and
+    angles between near neighbours: 25 steps in two calls against the oracle (state 1e-8, energies 1e-9, thermostat scalars 1e-8)."""
+    case = add_random_dynamics(random_case(100 + seed, vel=0.3), seed)
+    o = oracle.Oracle(case)
+    o.forces(2 if case.get("bonds") is not None else 0)
+    e = engine(case)
+    for n in (7, 18):
+        e.step(n)
+        o.step(n)
+    s, so, st, sto = e.state(), o.state(), e.stats(), o.stats()
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(s[k], so[k]) < 1e-8, (seed, k, rel_err(s[k], so[k]))
+    if case.get("tstat_type") == 2:
+        assert rel_err(s["U"], so["U"]) < 1e-8 and rel_err(s["radius"], so["rad"]) < 1e-8
+    for a, b in (("engVdW", "engVdW"), ("engCoul", "engElec3"), ("engKin", "engKin"), ("engTot", "engTot"), ("engBond", "engBond"),
+                 ("engAngle", "engAngle"), ("engTemp", "engTemp"), ("engCoulRec", "engElec2")):
+        assert abs(st[a] - sto[b]) <= 1e-9 * abs(sto[b]) + 1e-10, (seed, a, st[a], sto[b])
+    assert abs(st["nose_chit"] - sto["chit"]) <= 1e-8 * abs(sto["chit"]) + 1e-14
 
 
 def _raw_case(pos, box, eps=0.01006, sigma=3.3952):

@@ -51,7 +51,7 @@ def family_with_coulomb(family, elec, **kw):
     return base
 
 
-def random_case(seed, x_cells=0):
+def random_case(seed, x_cells=0, vel=1.0):
     """A random small system: box shape, density, cut-off, cell edge (below and above the cut-off), 1-3 species, potential family mix,
     electrostatics, external field - whatever the input surface allows for the pair path."""
     rng = np.random.default_rng(1000 + seed)
@@ -93,7 +93,7 @@ def random_case(seed, x_cells=0):
         charges[0] = 0.0                                        # a neutral species among charged ones
     case = {"box": [float(v) for v in box], "dt": 0.0005, "nsteps": 0, "species": [(float(rng.uniform(10, 60)), float(q)) for q in charges],
             "vdw": vdw, "types": types, "x": pos[:, 0].copy(), "y": pos[:, 1].copy(), "z": pos[:, 2].copy(),
-            "vx": rng.normal(0, 1.0, N), "vy": rng.normal(0, 1.0, N), "vz": rng.normal(0, 1.0, N),
+            "vx": rng.normal(0, vel, N), "vy": rng.normal(0, vel, N), "vz": rng.normal(0, vel, N),
             "elec_type": {"none": 0, "dir": 1, "ewald": 2, "fenn": 3}[elec], "rReal": rc if elec != "none" else 0.0,
             "alpha": float(rng.uniform(0.3, 0.55)) if elec in ("fenn", "ewald") else 0.0, "use_clist": 1,
             "cell_list": rc * float(rng.choice([0.45, 0.7, 1.0, 1.3]) if not x_cells else rng.choice([1.0, 1.15])), "Ux": float(rng.choice([0.0, 0.01])), "Uy": 0.0, "Uz": float(rng.choice([0.0, -0.02]))}
@@ -101,4 +101,55 @@ def random_case(seed, x_cells=0):
         case["ewald_k"] = tuple(int(v) for v in rng.integers(3, 8, size=3))
     if elec != "none" and not np.any(charges != 0.0):
         case["elec_type"] = 0
+    return case
+
+
+def add_random_dynamics(case, seed):
+    """Decorate a random_case with a thermostat / equilibration schedule and with bonds + angles between near neighbours."""
+    rng = np.random.default_rng(5000 + seed)
+    case = dict(case)
+    mode = ["none", "nose", "radi", "equil"][int(rng.integers(0, 4))]
+    case["T"] = float(rng.uniform(80.0, 400.0))
+    if mode == "nose":
+        case.update(tstat_type=1, tau=float(rng.uniform(0.02, 0.2)))
+    elif mode == "radi":
+        case.update(tstat_type=2, radii=[(2.73, 4.731, 0.2)] * len(case["species"]))
+    if mode in ("equil", "nose") or rng.random() < 0.3:
+        case.update(nEq=int(rng.integers(4, 15)), freqEq=int(rng.integers(1, 5)))
+    if rng.random() < 0.6:
+        box = np.array(case["box"])
+        pos = np.stack([case["x"], case["y"], case["z"]], axis=1)
+        types = np.asarray(case["types"])
+        N = len(types)
+        d = pos[:, None, :] - pos[None, :, :]
+        d -= box * np.round(d / box)
+        r = np.sqrt((d ** 2).sum(-1)) + np.eye(N) * 1e9
+        nn = np.argsort(r, axis=1)[:, :2]
+        rmax = 0.45 * min(case.get("rReal") or 1e9, max(v[3] for v in case["vdw"]) if case["vdw"] else 1e9, 0.49 * box.min())
+        btype, bond_types, bonds, angle_types, atype, angles, seen = {}, [], [], [], {}, [], set()
+        for i in rng.permutation(N)[: N // 3]:
+            js = [int(j) for j in nn[i] if r[i, j] < rmax]
+            for j in js:
+                key = (min(i, j), max(i, j))
+                if key in seen:
+                    continue
+                seen.add(key)
+                sp = (int(types[i]), int(types[j]))
+                if sp not in btype and sp[::-1] not in btype:
+                    kind = int(rng.integers(1, 3))
+                    r0 = float(r[i, j])
+                    bond_types.append((sp[0], sp[1], kind, [8.0, r0] if kind == 1 else [1.5, 1.2, r0, 0.3]))
+                    btype[sp] = len(bond_types)
+                t = btype.get(sp) or btype[sp[::-1]]
+                bonds.append((int(i), j, t))
+            if len(js) == 2 and r[js[0], js[1]] < 2 * rmax:
+                c = int(types[i])
+                if c not in atype:
+                    angle_types.append((c, 1, [float(rng.uniform(0.5, 2.0)), float(rng.uniform(-0.6, 0.2))]))
+                    atype[c] = len(angle_types)
+                angles.append((int(i), js[0], js[1], atype[c]))
+        if bonds:
+            case.update(bond_types=bond_types, bonds=np.array(bonds, dtype=np.int32))
+            if angles:
+                case.update(angle_types=angle_types, angles=np.array(angles, dtype=np.int32))
     return case
