@@ -61,6 +61,9 @@ def main():
     elif name == "ewald":    # structure factors are summed over the ranks every step
         case = inputs.lj_case((14, 5, 5), a=5.26, seed=8, rc=6.5, cell_list=6.5, charges=(0.4, -0.4), elec="fenn", r_real=6.5, alpha=0.45, vel_T=300.0)
         case.update(elec_type=2, ewald_k=(8, 5, 5))
+    elif name.startswith("dyn"):    # random system + thermostat / equilibration schedule / bonds and angles
+        from util import add_random_dynamics, random_case
+        case = add_random_dynamics(random_case(100 + int(name[3:]), x_cells=2 * world + 2, vel=0.3), int(name[3:]))
     elif name.startswith("rand"):   # seeded random system (tests/util.py random_case), box stretched along x to fit the ranks
         from util import random_case
         case = random_case(int(name[4:]), x_cells=2 * world + 2)

@@ -43,6 +43,16 @@ def test_slabs_on_random_systems(seed, nranks):
     assert out["species_cross_equal"]
 
 
+@pytest.mark.parametrize("seed,nranks", [(2, 2), (7, 2), (9, 3), (13, 2)])
+def test_slabs_on_random_dynamics(seed, nranks):
+    """random systems with the radiative / Nose-Hoover thermostat, equilibration rescaling (all-rank kinetic energy) and bonded
+    terms that straddle the slab boundaries"""
+    out = run_ranks(nranks, "dyn%d" % seed, 20, port=29660 + seed)
+    assert out["every_atom_owned_once"] and out["owned_total"] == out["n_atoms"]
+    assert out["max_rel_err_vs_single"] < 1e-8, out["errs"]
+    assert all(v < 1e-8 for v in out["energy_rel"].values()), out["energy_rel"]
+
+
 def test_slabs_with_deferred_half_kick():
     """debug bit 256: the large-system path (second half-kick applied by the next step's k_integrate1_bin, which in slab mode also
     packs the migrants and the halo from the freshly kicked velocities)."""
