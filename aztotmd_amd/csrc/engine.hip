@@ -162,10 +162,11 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
         {
             if (p.type == 0) continue;
             if (p.use_radii || p.type < AZTOT_VDW_LJ || p.type > AZTOT_VDW_BHM) uniform = false;
-            if (family == 0) family = p.type; else if (family != p.type) uniform = false;
+            if (family == 0) family = p.type; else if (family != p.type) family = 5;   // 5: mixed families, type looked up per species pair
         }
         if (family == 0) family = AZTOT_VDW_LJ;          // charges only: any family does, nothing is inside a VdW cut-off
         if ((m.elec_type == AZTOT_ELEC_FENNEL || m.elec_type == AZTOT_ELEC_EWALD) && m.alpha * m.rReal > 4.0) uniform = false;
+        if (opt_.reserved[0] & 512) uniform = false;      // debug bit 512: take the generic kernel
         P_.pad1 = uniform ? 2 : 0;
         P_.vdwFamily = uniform ? family : 0;
     }

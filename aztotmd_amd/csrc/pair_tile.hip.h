@@ -66,7 +66,7 @@ __device__ __forceinline__ int ld_i32(const int32_t* __restrict__ base, int j)
 // rocprof shows the kernel VALU-issue bound (VALU busy ~85 %), so this is all about instructions per wave: constant
 // LDS offsets (NS is a template parameter), no bounds clamps (far-away dummies pad the tile), Newton-refined
 // v_rcp_f64, branch-free potential.
-constexpr int kPairTabStride = 8;   // {p0..p4, r2cut, kqq, aux} per ordered species pair
+constexpr int kPairTabStride = 10;  // {p0..p4, r2cut, kqq, aux, potential type, -} per ordered species pair
 constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-Jones / charge-product table in LDS
 
 template <int MODE, int VDW, int LG>
@@ -169,24 +169,32 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 {
                     const double w = vdwOk ? 1.0 : 0.0;
                     const double r4i = r2i * r2i, r6i = r4i * r2i;
+                    const int pt = (VDW == 5) ? (int)pp[8] : VDW;                  // VDW 5: the families are mixed - per-pair type, divergent
                     double e;
-                    if (VDW == 2)
+                    if (pt == 1)
+                    {   // fer_lj vdw.cpp:16-26
+                        const double sr2 = pp[1] * r2i, sr6 = sr2 * sr2 * sr2;
+                        e = pp[0] * sr6 * (sr6 - 1.0);
+                        f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
+                    }
+                    else if (pt == 2)
                     {   // fer_buckingham vdw.cpp:60-70: A exp(-r/rho) - C/r^6 ; aux = 1/rho
                         const double ex = pp[0] * exp_nonpos(-r * pp[7]);
                         e = ex - pp[2] * r6i;
                         f = ex * ir * pp[7] - 6.0 * pp[2] * r4i * r4i;
                     }
-                    else if (VDW == 3)
+                    else if (pt == 3)
                     {   // fer_746 vdw.cpp:144-157: p0/r^7 - p1/r^4 - p2/r^6
                         e = r4i * (pp[0] * r2i * ir - pp[1] - pp[2] * r2i);
                         f = r6i * (7.0 * pp[0] * r2i * ir - 4.0 * pp[1] - 6.0 * pp[2] * r2i);
                     }
-                    else
+                    else if (pt == 4)
                     {   // fer_bhm vdw.cpp:102-112: A exp(B (sigma - r)) - C/r^6 - D/r^8
                         const double ex = pp[0] * exp_nonpos(pp[1] * (pp[2] - r));
                         e = ex - pp[3] * r6i - pp[4] * r4i * r4i;
                         f = pp[1] * ex * ir - 6.0 * pp[3] * r4i * r4i - 8.0 * pp[4] * r4i * r4i * r2i;
                     }
+                    else { e = 0.0; f = 0.0; }                                       // no potential for this species pair
                     acc.eV = fma(0.5 * w, e, acc.eV);
                     f *= w;
                 }
@@ -266,7 +274,8 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                 q[0] = v.p0; q[1] = v.p1; q[2] = v.p2; q[3] = v.p3; q[4] = v.p4;
                 q[5] = v.type ? v.r2cut : -1.0;                                   // no potential for this pair: never inside the cut-off
                 q[6] = (S.charged[a] && S.charged[b]) ? S.charge[a] * S.charge[b] * P.fcoul : 0.0;
-                q[7] = (VDW == 2 && v.type) ? 1.0 / v.p1 : 0.0;
+                q[7] = (v.type == 2) ? 1.0 / v.p1 : 0.0;                         // buck: 1/rho
+                q[8] = (double)v.type; q[9] = 0.0;
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -476,7 +485,8 @@ inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const D
     hipLaunchKernelGGL((k_pair_tile<MODE, VDW>), dim3(pair_tile_grid(P)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
 }
 
-// P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs), <= 4 species, no radii,
+// P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs; 5 = a mix of them,
+// selected per species pair), <= 4 species, no radii,
 // electrostatics none / direct / Fennell / Ewald with alpha rReal <= 4 (Engine::Engine decides)
 inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts*, const int32_t* cellStart,
                              double* partials, int maxBlocks, hipStream_t stream)
@@ -491,6 +501,7 @@ inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevP
         case 2: if (ew) launch_pair_tile_as<3, 2>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 2>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
         case 3: if (ew) launch_pair_tile_as<3, 3>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 3>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
         case 4: if (ew) launch_pair_tile_as<3, 4>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 4>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
+        case 5: if (ew) launch_pair_tile_as<3, 5>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 5>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
         }
     }
     launch_pair_tile_as<0, 0>(P, S, pots, A, cellStart, partials, maxBlocks, stream);
