@@ -66,7 +66,8 @@ __device__ __forceinline__ int ld_i32(const int32_t* __restrict__ base, int j)
 // rocprof shows the kernel VALU-issue bound (VALU busy ~85 %), so this is all about instructions per wave: constant
 // LDS offsets (NS is a template parameter), no bounds clamps (far-away dummies pad the tile), Newton-refined
 // v_rcp_f64, branch-free potential.
-constexpr int kPairTabStride = 10;  // {p0..p4, r2cut, kqq, aux, potential type, -} per ordered species pair
+constexpr int kPairTabStride = 8;   // {p0..p4, r2cut, kqq, potential type} per ordered species pair.  Not one byte more: the Coulomb
+                                    // kernels sit at 10 192 B of LDS, and 10 240 B is the limit for 16 waves per CU (+64 B cost 7 %)
 constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-Jones / charge-product table in LDS
 
 template <int MODE, int VDW, int LG>
@@ -108,11 +109,14 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
             // left-align: candidate number b of this word sits at bit 31 - b, whatever the word length
             m[w] = (nb > 0) ? (~miss << (32 - nb)) : 0u;
         }
-        if (P.pad0 & 2) { acc.fx += (double)(m[0] ^ m[1] ^ m[2]); m[0] = m[1] = m[2] = 0u; }
         // pass 2: every lane pops its own hits.  `cur` is the word being drained, `nxt`/`lst` the ones still waiting; when
         // `cur` runs dry the next word slides in (selects, no branches), so a lane keeps busy as long as ANY of its three
         // words has hits left - the wave loops max-over-lanes(hits per lane) times, not sum-over-words(max per word).
         // The body is branch-free: lanes without a hit run on a dummy candidate and are masked out.
+        // round-local accumulators (folded into `acc` after the loop): the loop-carried values then start from constants, which keeps
+        // the register allocator from copying five 64-bit accumulators around in every iteration
+        PairAcc rl = {0, 0, 0, 0, 0, 0};
+        PairAcc& ra = (MODE == 1) ? rl : acc;              // measured: helps the LJ kernel (312 -> 309 us), hurts the Coulomb ones (629 -> 664)
         uint32_t cur = m[0], nxt = m[1], lst = m[2];
         int kbase = rb * NS + slice;                       // tile index of bit 31 of `cur`
         while (__any((cur | nxt | lst) != 0u))
@@ -137,12 +141,12 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 const double r2i = fast_rcp(r2s);
                 const double sr2 = lj.p1 * r2i;
                 const double sr6 = sr2 * sr2 * sr2;
-                acc.eV = fma(0.5 * lj.p0, sr6 * (sr6 - 1.0), acc.eV);
+                ra.eV = fma(0.5 * lj.p0, sr6 * (sr6 - 1.0), ra.eV);
                 const double f = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
                 const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
                 nDropHalf += __popcll(__ballot(tooBig));
                 const double fm = tooBig ? 0.0 : f;
-                acc.fx = fma(fm, dx, acc.fx); acc.fy = fma(fm, dy, acc.fy); acc.fz = fma(fm, dz, acc.fz);
+                ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
             }
             else if (MODE >= 2)
             {   // one potential family for every species pair (VDW: 1 lnjs, 2 buck, 3 p746, 4 bmhs - fer_* of vdw.cpp:16-157), electrostatics
@@ -162,14 +166,14 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 {   // fer_lj vdw.cpp:16-26: p0 = 4 eps, p1 = sigma^2, p2 = 24 eps
                     const double sr2 = vdwOk ? pp[1] * r2i : 0.0;
                     const double sr6 = sr2 * sr2 * sr2;
-                    acc.eV = fma(0.5 * pp[0], sr6 * (sr6 - 1.0), acc.eV);
+                    ra.eV = fma(0.5 * pp[0], sr6 * (sr6 - 1.0), ra.eV);
                     f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
                 }
                 else
                 {
                     const double w = vdwOk ? 1.0 : 0.0;
                     const double r4i = r2i * r2i, r6i = r4i * r2i;
-                    const int pt = (VDW == 5) ? (int)pp[8] : VDW;                  // VDW 5: the families are mixed - per-pair type, divergent
+                    const int pt = (VDW == 5) ? (int)pp[7] : VDW;                  // VDW 5: the families are mixed - per-pair type, divergent
                     double e;
                     if (pt == 1)
                     {   // fer_lj vdw.cpp:16-26
@@ -178,10 +182,10 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                         f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
                     }
                     else if (pt == 2)
-                    {   // fer_buckingham vdw.cpp:60-70: A exp(-r/rho) - C/r^6 ; aux = 1/rho
-                        const double ex = pp[0] * exp_nonpos(-r * pp[7]);
+                    {   // fer_buckingham vdw.cpp:60-70: A exp(-r/rho) - C/r^6 ; 1/rho in slot 3
+                        const double ex = pp[0] * exp_nonpos(-r * pp[3]);
                         e = ex - pp[2] * r6i;
-                        f = ex * ir * pp[7] - 6.0 * pp[2] * r4i * r4i;
+                        f = ex * ir * pp[3] - 6.0 * pp[2] * r4i * r4i;
                     }
                     else if (pt == 3)
                     {   // fer_746 vdw.cpp:144-157: p0/r^7 - p1/r^4 - p2/r^6
@@ -195,7 +199,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                         f = pp[1] * ex * ir - 6.0 * pp[3] * r4i * r4i - 8.0 * pp[4] * r4i * r4i * r2i;
                     }
                     else { e = 0.0; f = 0.0; }                                       // no potential for this species pair
-                    acc.eV = fma(0.5 * w, e, acc.eV);
+                    ra.eV = fma(0.5 * w, e, ra.eV);
                     f *= w;
                 }
                 if (MODE == 2 && P.elec_type == 3)
@@ -204,7 +208,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                     const double ar = P.alpha * r;
                     const double ex = exp_nonpos(-ar * ar);
                     const double erfcar = erfc_given_exp(ar, ex);
-                    acc.eC = fma(0.5 * kqq, erfcar * ir - P.el_scale + P.el_scale2 * (r - P.rReal), acc.eC);
+                    ra.eC = fma(0.5 * kqq, erfcar * ir - P.el_scale + P.el_scale2 * (r - P.rReal), ra.eC);
                     f = fma(kqq * ir, (erfcar * r2i + P.daipi2 * ex * ir) - P.el_scale2, f);
                 }
                 else if (MODE == 3)
@@ -213,23 +217,24 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                     const double ar = P.alpha * r;
                     const double ex = exp_nonpos(-ar * ar);
                     const double erfcar = erfc_given_exp(ar, ex);
-                    acc.eC = fma(0.5 * kqq, erfcar * ir, acc.eC);
+                    ra.eC = fma(0.5 * kqq, erfcar * ir, ra.eC);
                     f = fma(kqq * ir * r2i, fma(P.daipi2 * r, ex, erfcar), f);
                 }
                 else if (MODE == 2 && P.elec_type == 1)
                 {   // direct_coul elec.cpp:415-428
                     const double kqq = pairOk ? pp[6] : 0.0;
-                    acc.eC = fma(0.5 * kqq, ir, acc.eC);
+                    ra.eC = fma(0.5 * kqq, ir, ra.eC);
                     f = fma(kqq * ir, r2i, f);
                 }
                 const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
                 nDropHalf += __popcll(__ballot(tooBig));
                 const double fm = tooBig ? 0.0 : f;
-                acc.fx = fma(fm, dx, acc.fx); acc.fy = fma(fm, dy, acc.fy); acc.fz = fma(fm, dz, acc.fz);
+                ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
             }
             else if (live && r2 > 0.0 && r2 <= P.r2Max)
-                pair_visit(P, S, pots, dx, dy, dz, r2, ti, ttyp[k], radi, trad[k], acc);
+                pair_visit(P, S, pots, dx, dy, dz, r2, ti, ttyp[k], radi, trad[k], ra);
         }
+        if (MODE == 1) { acc.fx += rl.fx; acc.fy += rl.fy; acc.fz += rl.fz; acc.eV += rl.eV; }
     }
     // dropped pairs were counted per wave (ballot popcount); book the wave total on lane 0 in "half pair" units
     if (MODE != 0 && threadIdx.x == 0) acc.dropped += 0.5 * (double)nDropHalf;
@@ -274,8 +279,9 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                 q[0] = v.p0; q[1] = v.p1; q[2] = v.p2; q[3] = v.p3; q[4] = v.p4;
                 q[5] = v.type ? v.r2cut : -1.0;                                   // no potential for this pair: never inside the cut-off
                 q[6] = (S.charged[a] && S.charged[b]) ? S.charge[a] * S.charge[b] * P.fcoul : 0.0;
-                q[7] = (v.type == 2) ? 1.0 / v.p1 : 0.0;                         // buck: 1/rho
-                q[8] = (double)v.type; q[9] = 0.0;
+                if (v.type == 2) q[3] = 1.0 / v.p1;                              // buck uses p0..p2 only: 1/rho rides in the p3 slot
+                q[7] = (double)v.type;
+
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -313,12 +319,9 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                     if (MODE == 0) trad[T + lane] = 0.0;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (!(P.pad0 & 1))
-                {
-                    if (lg == 4) tile_passes<MODE, VDW, 4>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
-                    else if (lg == 5) tile_passes<MODE, VDW, 5>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
-                    else tile_passes<MODE, VDW, 6>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
-                }
+                if (lg == 4) tile_passes<MODE, VDW, 4>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
+                else if (lg == 5) tile_passes<MODE, VDW, 5>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
+                else tile_passes<MODE, VDW, 6>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
                 __builtin_amdgcn_wave_barrier();
                 T = 0;
             };
