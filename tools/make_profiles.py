@@ -43,7 +43,7 @@ with open(os.path.join(P, "%s_rocprofv3_pmc_hbm_traffic.csv" % tag), "w", newlin
 tp = os.path.join(P, "pmc_traffic.json")
 rec = json.load(open(tp)) if os.path.exists(tp) else {}
 for r in rows:
-    name = {"k_pair_tile<1>": "pair_tile", "k_pair_tile<0>": "pair_tile", "k_pair_atom": "pair_atom"}.get(r["kernel"])
+    name = "pair_tile" if r["kernel"].startswith("k_pair_tile<") else ("pair_atom" if r["kernel"] == "k_pair_atom" else None)
     if name:
         rec["%s:%s:%d" % (workload, name, ngpu)] = {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"], "round": tag, "kernel": r["kernel"],
                                                     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH doubled per MI355X_MICROARCH.md"}
