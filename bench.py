@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--cell-size", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline sample (0: sized for ~15 s)")
-    ap.add_argument("--debug", type=int, default=0, help="kernel ablation switches (results invalid)")
+    ap.add_argument("--debug", type=int, default=0,
+                    help="engine path switches for A/B measurements: 128 k_integrate2 every step, 256 large-system kick path, 512 generic pair kernel")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="measurement aid: time rank 0 of an N-rank slab run on one GPU (loopback halo)")
     ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels (enables hipGraph replay)")
     return ap.parse_args()

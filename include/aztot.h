@@ -130,7 +130,8 @@ typedef struct
     double cell_size;            /* 0: derive from control.cell_list / cut-off; >0: force this cell edge */
     int32_t use_graph;           /* 1: replay the step as a captured hipGraph when possible */
     int32_t profile;             /* 1: time every kernel with HIP events (aztot_kernel_times) */
-    int32_t reserved[8];
+    int32_t reserved[8];         /* [0]: path switches for A/B measurements, results unchanged (128: k_integrate2 every step, 256: large-system
+                                    kick path, 512: generic pair kernel); [1]: 1 = loopback slab transport (one rank of N talks to itself: timing aid) */
 } aztot_options;
 
 /* per-step scalars: the fields tracked by stat.dat (cuStat.cu:241-261) + serial calc_chars (integrators.cpp:63-73) */
