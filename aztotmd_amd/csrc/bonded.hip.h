@@ -57,12 +57,17 @@ __device__ __forceinline__ double bond_force(const DevBondType& b, double r2, do
     return 0.0;
 }
 
+// VERIFY (slab ranks): the map may hold a stale entry for an atom that left this rank, so the id is read back; on one GPU every
+// atom is resident and every entry was written by the sort that has just run
+template <bool VERIFY>
 __device__ __forceinline__ int resident_index(const BondedTables& B, const AtomArrays& A, int id, int nTotal)
 {
     const int j = B.idxOfId[id];
+    if (!VERIFY) return j;
     return (j >= 0 && j < nTotal && A.id[j] == id) ? j : -1;
 }
 
+template <bool VERIFY>
 __global__ __launch_bounds__(kBlock) void k_bonded(StepParams P, AtomArrays A, Counts* __restrict__ cnt, BondedTables B,
                                                    double* __restrict__ partials, int maxBlocks)
 {
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_bonded(StepParams P, AtomArrays A, C
         for (int k = B.bondStart[me], ke = B.bondStart[me + 1]; k < ke; k++)
         {
             const BondEntry en = B.bondEnt[k];
-            const int j = resident_index(B, A, en.partner, nTotal);
+            const int j = resident_index<VERIFY>(B, A, en.partner, nTotal);
             if (j < 0) { missing = true; continue; }
             double dx = xi - A.x[j], dy = yi - A.y[j], dz = zi - A.z[j];       // sqr_distance_proj, box.cpp:327-335
             min_image(dx, P.L[0], P.half[0]); min_image(dy, P.L[1], P.half[1]); min_image(dz, P.L[2], P.half[2]);
@@ -92,9 +97,9 @@ __global__ __launch_bounds__(kBlock) void k_bonded(StepParams P, AtomArrays A, C
         {   // angle_iter angles.cpp:179-227 ; angle_hcos cuAngles.cu:230-284
             const AngleEntry en = B.angEnt[k];
             const int role = en.roleType & 3;
-            const int jc = (role == 0) ? i : resident_index(B, A, en.c, nTotal);
-            const int j1 = (role == 1) ? i : resident_index(B, A, en.l1, nTotal);
-            const int j2 = (role == 2) ? i : resident_index(B, A, en.l2, nTotal);
+            const int jc = (role == 0) ? i : resident_index<VERIFY>(B, A, en.c, nTotal);
+            const int j1 = (role == 1) ? i : resident_index<VERIFY>(B, A, en.l1, nTotal);
+            const int j2 = (role == 2) ? i : resident_index<VERIFY>(B, A, en.l2, nTotal);
             if (jc < 0 || j1 < 0 || j2 < 0) { missing = true; continue; }
             const DevAngleType at = B.atypes[en.roleType >> 2];
             const double xc = A.x[jc], yc = A.y[jc], zc = A.z[jc];

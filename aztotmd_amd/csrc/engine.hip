@@ -560,7 +560,10 @@ void Engine::sort_and_forces(bool integrate_first, bool withBonded)
     if (hasEwald_) launch_ewald();
     if (hasBonded_ && withBonded)      // exec_bondlist + exec_anglelist, main.cpp:101-104 (GPU path: main.cu:307-312,353-363)
         timed("bonded", [&] {
-            hipLaunchKernelGGL(k_bonded, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, cur(), dCounts_, bonded_, dPartials_, maxBlocks_);
+            if (nranks_ > 1)
+                hipLaunchKernelGGL(k_bonded<true>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, cur(), dCounts_, bonded_, dPartials_, maxBlocks_);
+            else
+                hipLaunchKernelGGL(k_bonded<false>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, cur(), dCounts_, bonded_, dPartials_, maxBlocks_);
         });
 }
 
