@@ -86,7 +86,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
 
 EXPORTS = ("aztot_init_md", "aztot_model_create", "aztot_model_set_bonded", "aztot_model_query", "aztot_model_species_name", "aztot_free_md", "aztot_default_options",
            "aztot_init_device", "aztot_free_device", "aztot_step", "aztot_forces", "aztot_get_stats", "aztot_species_crossings", "aztot_md_to_host",
-           "aztot_set_state", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id", "aztot_comm_selftest",
+           "aztot_set_state", "aztot_cell_table", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id", "aztot_comm_selftest", "aztot_comm_ranks",
            "aztot_init_device_slab", "aztot_last_error", "aztot_version")
 
 
@@ -137,11 +137,13 @@ def lib():
         L.aztot_species_crossings.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
         L.aztot_md_to_host.argtypes = [C.c_void_p, C.POINTER(_State)]
         L.aztot_set_state.argtypes = [C.c_void_p, C.POINTER(_State)]
+        L.aztot_cell_table.argtypes = [C.c_void_p, _ip, _ip, C.c_int, _ip, C.c_int]
         L.aztot_kernel_times.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.POINTER(C.c_int64), C.c_int]
         L.aztot_reset_kernel_times.argtypes = [C.c_void_p]
         L.aztot_set_profile.argtypes = [C.c_void_p, C.c_int]
         L.aztot_comm_make_id.argtypes = [C.c_void_p]
         L.aztot_comm_selftest.argtypes = [C.c_int]
+        L.aztot_comm_ranks.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -360,6 +362,20 @@ class Engine:
             keep.append(a)
             setattr(st, k, a.ctypes.data_as(_dp))
         _check(lib().aztot_set_state(self.h, C.byref(st)))
+
+    def cell_table(self):
+        """(dims, cell_start[n_cells + 1], atom_id[resident atoms]) of the sorted cell list the device holds."""
+        dims = np.zeros(3, dtype=np.int32)
+        n = _check(lib().aztot_cell_table(self.h, dims.ctypes.data_as(_ip), None, 0, None, 0))
+        start = np.zeros(n + 1, dtype=np.int32)
+        _check(lib().aztot_cell_table(self.h, dims.ctypes.data_as(_ip), start.ctypes.data_as(_ip), n + 1, None, 0))
+        ids = np.zeros(max(int(start[-1]), 1), dtype=np.int32)
+        _check(lib().aztot_cell_table(self.h, dims.ctypes.data_as(_ip), start.ctypes.data_as(_ip), n + 1, ids.ctypes.data_as(_ip), ids.size))
+        return tuple(int(v) for v in dims), start, ids[:int(start[-1])]
+
+    def comm_ranks(self):
+        """ranks of the RCCL communicator carrying the halo (0: no RCCL in use)."""
+        return _check(lib().aztot_comm_ranks(self.h))
 
     def kernel_times(self):
         names = C.create_string_buffer(4096)

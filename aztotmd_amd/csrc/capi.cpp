@@ -272,6 +272,14 @@ int aztot_set_state(aztot_md* md, const aztot_state* in)
     return guarded([&] { md->eng->set_state(*in); });
 }
 
+int aztot_cell_table(aztot_md* md, int32_t dims[3], int32_t* cell_start, int cap_cells, int32_t* atom_id, int cap_atoms)
+{
+    if (!md || !md->eng || !dims) return fail(AZTOT_ERR_ARG, "null argument");
+    int n = 0;
+    const int rc = guarded([&] { n = md->eng->cell_table(dims, cell_start, cap_cells, atom_id, cap_atoms); });
+    return rc < 0 ? rc : n;
+}
+
 int aztot_kernel_times(aztot_md* md, char* names, int cap, double* ms, int64_t* calls, int max_kernels)
 {
     if (!md) return fail(AZTOT_ERR_ARG, "null handle");
@@ -309,6 +317,14 @@ int aztot_comm_make_id(void* id_bytes)
 {
     if (!id_bytes) return fail(AZTOT_ERR_ARG, "null argument");
     return guarded([&] { RcclExchanger::make_id(id_bytes); });
+}
+
+int aztot_comm_ranks(aztot_md* md)
+{
+    if (!md || !md->eng) return fail(AZTOT_ERR_ARG, "null handle");
+    int n = 0;
+    const int rc = guarded([&] { n = md->eng->comm_ranks(); });
+    return rc < 0 ? rc : n;
 }
 
 int aztot_comm_selftest(int device)

@@ -42,12 +42,18 @@ public:
     void species_crossings(int64_t* out, int cap);
     void md_to_host(aztot_state& out);
     void set_state(const aztot_state& in);
+    int cell_table(int32_t dims[3], int32_t* cellStart, int capCells, int32_t* atomId, int capAtoms);
     int kernel_times(std::vector<KernelTimer>& out);
     void reset_kernel_times();
     void set_profile(bool on) { sync(); profile_ = on; }
     int n_atoms_global() const { return model_.nAt; }
+    int comm_ranks() const { return xch_ ? xch_->comm_ranks() : 0; }
 
 private:
+    void construct();
+    void release();
+    void destroy_graphs();
+    void check_launch(const char* where);
     void choose_cells();
     void allocate();
     void upload_initial();

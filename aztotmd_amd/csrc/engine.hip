@@ -124,6 +124,12 @@ void Engine::choose_cells()
 Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nranks, Exchanger* xch)
     : model_(model), opt_(opt), rank_(rank), nranks_(nranks), xch_(xch)
 {
+    try { construct(); }
+    catch (...) { release(); throw; }      // ~Engine does not run for a constructor that throws: free the stream and every allocation here
+}
+
+void Engine::construct()
+{
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -203,18 +209,37 @@ Engine::Engine(const Model& model, const aztot_options& opt, int rank, int nrank
     upload_initial();
 }
 
-Engine::~Engine()
+Engine::~Engine() { release(); }
+
+void Engine::destroy_graphs()
 {
-    if (stream_) (void)hipStreamSynchronize(stream_);
     for (int g = 0; g < 2; g++)
     {
         if (graphExec_[g]) (void)hipGraphExecDestroy(graphExec_[g]);
         if (graph_[g]) (void)hipGraphDestroy(graph_[g]);
+        graphExec_[g] = nullptr; graph_[g] = nullptr;
     }
+}
+
+void Engine::release()
+{
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    destroy_graphs();
     for (auto& p : pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    pending_.clear();
     for (auto e : eventPool_) (void)hipEventDestroy(e);
+    eventPool_.clear();
     for (void* p : allocs_) (void)hipFree(p);
+    allocs_.clear();
     if (stream_) (void)hipStreamDestroy(stream_);
+    stream_ = nullptr;
+}
+
+// a rejected launch configuration (too much LDS, bad grid) is reported by hipGetLastError only: hipStreamSynchronize stays silent
+void Engine::check_launch(const char* where)
+{
+    if (capturing_) return;
+    check_hip(hipGetLastError(), where);
 }
 
 void Engine::allocate()
@@ -408,6 +433,19 @@ void Engine::upload_ewald()
     ew_.S = (double*)alloc(sizeof(double) * 2 * (size_t)ew_.nK);
     HIP_CHECK(hipMemset(ew_.S, 0, sizeof(double) * 2 * (size_t)ew_.nK));
     ew_.scale = m.el_scale; ew_.scale2 = m.el_scale2;
+    {   // both kernels keep the three per-atom harmonic tables in dynamic LDS: 1 KiB per harmonic (+ 12 KiB of force slices).  Beyond
+        // the default 64 KiB a kernel has to be told (up to the CU's 160 KiB); beyond that the sum cannot run in this layout
+        const size_t ldsTab = sizeof(double) * 2 * (size_t)kEwTile * (ew_.kx + ew_.ky + ew_.kz);
+        const size_t ldsForce = ldsTab + sizeof(double) * 3 * kEwTile * kEwSlices;
+        int devMax = 0;
+        HIP_CHECK(hipDeviceGetAttribute(&devMax, hipDeviceAttributeMaxSharedMemoryPerBlock, opt_.device));
+        const size_t hwMax = std::max<size_t>((size_t)devMax, 160 * 1024);
+        if (ldsForce > hwMax)
+            throw std::runtime_error("elec pme: kx + ky + kz = " + std::to_string(ew_.kx + ew_.ky + ew_.kz) + " harmonics need " + std::to_string(ldsForce) +
+                                     " B of LDS per workgroup, more than the " + std::to_string(hwMax) + " B a CU has (use fewer k-vectors or elec fenn)");
+        if (ldsTab > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_ewald_sfac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTab));
+        if (ldsForce > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_ewald_force, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsForce));
+    }
     DevStats s;
     HIP_CHECK(hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost));
     s.engCoulConst = m.engElec1;
@@ -429,6 +467,7 @@ void Engine::launch_ewald()
         hipLaunchKernelGGL(k_ewald_force, dim3(div_up(capacity_, kEwTile)), dim3(kEwTile * kEwSlices), lds + sizeof(double) * 3 * kEwTile * kEwSlices,
                            stream_, P_, S_, cur(), dCounts_, ew_);
     });
+    check_launch("Ewald kernels");
 }
 
 void Engine::upload_initial()
@@ -565,6 +604,7 @@ void Engine::sort_and_forces(bool integrate_first, bool withBonded)
             else
                 hipLaunchKernelGGL(k_bonded<false>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, cur(), dCounts_, bonded_, dPartials_, maxBlocks_);
         });
+    check_launch("sort + force kernels");
 }
 
 void Engine::collect_and_finalize(unsigned slotMask)
@@ -661,12 +701,25 @@ void Engine::step(int nsteps)
         const int g = cur_;
         if (!graphExec_[g])
         {
-            capturing_ = true;
+            const int curBefore = cur_;
             HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-            launch_step_kernels();
-            launch_step_kernels();
-            HIP_CHECK(hipStreamEndCapture(stream_, &graph_[g]));
+            capturing_ = true;
+            try
+            {
+                launch_step_kernels();
+                launch_step_kernels();
+            }
+            catch (...)
+            {   // leave neither the stream in capture mode nor the engine believing it is capturing
+                hipGraph_t broken = nullptr;
+                (void)hipStreamEndCapture(stream_, &broken);
+                if (broken) (void)hipGraphDestroy(broken);
+                capturing_ = false;
+                cur_ = curBefore;
+                throw;
+            }
             capturing_ = false;
+            HIP_CHECK(hipStreamEndCapture(stream_, &graph_[g]));
             HIP_CHECK(hipGraphInstantiate(&graphExec_[g], graph_[g], nullptr, nullptr, 0));
             // the capture itself executed nothing and left cur_ where it was
         }
@@ -675,6 +728,7 @@ void Engine::step(int nsteps)
     for (; done < nsteps; done++) launch_step_kernels();
     kickOwed_ = lazyKick_;          // set here, not in launch_step_kernels: a replayed graph does not pass through the host code
     finish_steps();
+    check_launch("step kernels");
     sync();
     check_overflow();
 }
@@ -772,6 +826,27 @@ void Engine::md_to_host(aztot_state& out)
     out.n_atoms = n;   // number of atoms this rank wrote
 }
 
+// read-back of the sorted cell list (cudaMD::firstAtomInCell + the id of the atom in every slot)
+int Engine::cell_table(int32_t dims[3], int32_t* cellStart, int capCells, int32_t* atomId, int capAtoms)
+{
+    sync();
+    dims[0] = P_.ncxLocal; dims[1] = P_.nc[1]; dims[2] = P_.nc[2];
+    const int nCell = P_.nCellLocal;
+    if (cellStart)
+    {
+        if (capCells < nCell + 1) throw std::runtime_error("cell_table: cell_start needs n_cells + 1 entries");
+        HIP_CHECK(hipMemcpy(cellStart, dCellStart_, sizeof(int32_t) * (size_t)(nCell + 1), hipMemcpyDeviceToHost));
+    }
+    if (atomId)
+    {
+        Counts c;
+        HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
+        if (capAtoms < c.nTotal) throw std::runtime_error("cell_table: atom_id array too small");
+        HIP_CHECK(hipMemcpy(atomId, cur().id, sizeof(int32_t) * (size_t)c.nTotal, hipMemcpyDeviceToHost));
+    }
+    return nCell;
+}
+
 // overwrite per-atom state (indexed by ORIGINAL atom id); used for exact restarts and stage-wise tests
 void Engine::set_state(const aztot_state& in)
 {
@@ -790,7 +865,11 @@ void Engine::set_state(const aztot_state& in)
     AtomArrays& A = cur();
     up(in.x, A.x); up(in.y, A.y); up(in.z, A.z); up(in.vx, A.vx); up(in.vy, A.vy); up(in.vz, A.vz);
     up(in.fx, A.fx); up(in.fy, A.fy); up(in.fz, A.fz); up(in.U, A.U); up(in.radius, A.rad);
-    if (in.U || in.radius) thermoTouched_ = true;      // from now on the sort carries the per-atom thermostat state along
+    if ((in.U || in.radius) && !thermoTouched_)
+    {   // from now on the sort carries the per-atom thermostat state along; a captured graph has the old carry mode baked in
+        thermoTouched_ = true;
+        destroy_graphs();
+    }
 }
 
 }  // namespace aztot

@@ -88,6 +88,7 @@ struct RcclApi
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -107,6 +108,7 @@ RcclApi& rccl()
     api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
     api.Send = (decltype(api.Send))sym("ncclSend");
     api.Recv = (decltype(api.Recv))sym("ncclRecv");
     api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
@@ -144,6 +146,13 @@ RcclExchanger::~RcclExchanger()
 {
     if (dScratch_) (void)hipFree(dScratch_);
     if (comm_) rccl().CommDestroy((ncclComm_t)comm_);
+}
+
+int RcclExchanger::comm_ranks() const
+{
+    int n = 0;
+    check_nccl(rccl().CommCount((ncclComm_t)comm_, &n), "ncclCommCount");
+    return n;
 }
 
 void RcclExchanger::exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight,

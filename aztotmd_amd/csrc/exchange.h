@@ -28,6 +28,8 @@ public:
     // exchange step of the path, once per force evaluation)
     virtual void allreduce_device(double* dev, int n, hipStream_t stream) = 0;
     virtual bool device_side() const = 0;
+    // ranks of the RCCL communicator that carries the halo (ncclCommCount); 0 for every other transport
+    virtual int comm_ranks() const { return 0; }
 };
 
 class CallbackExchanger : public Exchanger
@@ -76,6 +78,7 @@ public:
     void allreduce_sum(double* host, int n, hipStream_t stream) override;
     void allreduce_device(double* dev, int n, hipStream_t stream) override;
     bool device_side() const override { return true; }
+    int comm_ranks() const override;
     static int id_bytes();
     static void make_id(void* out);
     // one-rank communicator on `device`: the ring exchange with itself (both messages, same call order as on N GPUs) and both

@@ -876,12 +876,14 @@ __global__ void k_finalize(StepParams P, DevStats* st, const double* __restrict_
     st->engCoul = sums[PS_ECOUL];
     st->engKin = sums[PS_EKIN];
     st->engTemp = sums[PS_ETEMP];
+    // running totals grow only by what THIS call collected: a slot outside slotMask still holds the previous call's window in
+    // local[] (aztot_forces after aztot_step collects the energies only and must leave the wall counters alone)
     for (int k = 0; k < 6; k++)
     {
-        st->mom[k] += sums[PS_MOM_XN + k];
-        st->cross[k] += (long long)(sums[PS_CNT_XN + k] + 0.5);
+        if ((slotMask >> (PS_MOM_XN + k)) & 1u) st->mom[k] += sums[PS_MOM_XN + k];
+        if ((slotMask >> (PS_CNT_XN + k)) & 1u) st->cross[k] += (long long)(sums[PS_CNT_XN + k] + 0.5);
     }
-    st->dropped += (long long)(sums[PS_DROPPED] + 0.5);
+    if ((slotMask >> PS_DROPPED) & 1u) st->dropped += (long long)(sums[PS_DROPPED] + 0.5);
     st->temperature = 2.0 * st->engKin * P.revDegFree * P.rkB;
     st->engBond = sums[PS_EBOND];
     st->engAngle = sums[PS_EANGLE];

@@ -26,8 +26,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12            # B/s, MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+FP64_VECTOR_PEAK = 78.6e12   # FLOP/s, FP64 vector (256 CUs x 128 FLOP/clk x 2.4 GHz)
 PAIR_BYTES_PER_ATOM = 52.0   # x,y,z,type read + fx,fy,fz written
 PAIR_BYTES_PER_CELL = 8.0    # cellStart/cellCount
+# algorithmic bytes per atom of the streaming kernels: the ones for which ">= 40 % of HBM peak" is the meaningful target
+STREAM_BYTES_PER_ATOM = {"integrate1_bin": 132.0, "place": 28.0, "rank_gather": 120.0, "integrate2": 76.0, "post_tstat": 84.0}
 
 
 def parse():
@@ -148,21 +151,35 @@ def main():
         t = torch.tensor([ok])
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if int(t.item()) == 0:
-            # RCCL could not be brought up on this node: fall back to the host-staged transport over gloo so that the
-            # run still produces a (slow, clearly labelled) number instead of nothing
+            if ok:
+                eng.close()                  # ranks whose engine came up: release it before anything else is built
+            if not oversubscribed:
+                # one GPU per rank and RCCL does not come up: that is a failed run, not a slower one - a scaling record must
+                # never report "ok" with the halo travelling through the host
+                if rank == 0:
+                    sys.stderr.write("bench.py: RCCL initialisation failed with one GPU per rank: %s\n" % (err if not ok else "on another rank"))
+                dist.barrier()
+                dist.destroy_process_group()
+                raise SystemExit(3)
+            # rehearsal on a box with fewer GPUs than ranks (RCCL cannot put two ranks on one device): host-staged transport over
+            # gloo, clearly labelled, never a result
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from slab_worker import make_transport
             sr, ar = make_transport()
             slab = {"rank": rank, "nranks": world, "sendrecv": sr, "allreduce": ar}
             eng = api.Engine(model, device=local_rank, initial_forces=1, pair_variant=a.pair_variant, cell_size=a.cell_size,
                              use_graph=0, profile=0, slab=slab, debug=a.debug)
-            transport = "host-staged over gloo (RCCL init failed)"
+            transport = "REHEARSAL: host-staged over gloo, ranks share GPUs - not a result"
 
     def barrier():
         if dist is not None:
             dist.barrier()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+
+    rccl_ranks = eng.comm_ranks()            # ncclCommCount of the communicator the halo travels on (0: no RCCL)
+    if world > 1 and not oversubscribed and rccl_ranks != world:
+        raise SystemExit("bench.py: %d ranks but the RCCL communicator has %d" % (world, rccl_ranks))
 
     # ---- timed region: EXACTLY a.steps steps, no per-kernel instrumentation (the step is replayed as a hipGraph on 1 GPU)
     eng.step(a.warmup)
@@ -209,7 +226,7 @@ def main():
             "config": {"workload": {"C4": "1 000 188 Ar, LJ rc 8.5 A, FCC 63^3 a=5.735 jitter 0.15, dt 1 fs, NVE (BASELINE config '1 000 000 Ar LJ', SURVEY C4)",
                                     "C3": "1 000 188 atoms, LJ rc 8.5 A + Fennell/DSF Coulomb q=+-0.2 (SURVEY C3)",
                                     "C2": "40 000 Ar, LJ rc 8.5 A (SURVEY C2)"}.get(a.workload, a.workload),
-                       "n_atoms": n_atoms, "n_cells": st["n_cells"], "decomposition": "single GPU" if world == 1 else "%d slabs along x" % world, "transport": transport, "ranks_share_gpus": oversubscribed,
+                       "n_atoms": n_atoms, "n_cells": st["n_cells"], "decomposition": "single GPU" if world == 1 else "%d slabs along x" % world, "transport": transport, "rccl_ranks": rccl_ranks, "ranks_share_gpus": oversubscribed,
                        "pair_variant": a.pair_variant,
                        "kernel_timing": "second pass of the same %d steps with HIP events on the engine stream" % a.steps if profile else "off"},
             "matom_steps_per_s": n_atoms * a.steps / wall / 1e6,
@@ -223,18 +240,38 @@ def main():
             if pair_name:
                 t_pair = kern[pair_name]["avg_us"] * 1e-6
                 alg = PAIR_BYTES_PER_ATOM * n_atoms / world + PAIR_BYTES_PER_CELL * st["n_cells"] / world
-                traffic = None
+                traffic = flop = None
+                rec = {}
                 tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
                 if os.path.exists(tp):
                     try:
-                        rec = json.load(open(tp)).get("%s:%s:%d" % (a.workload, pair_name, world))
-                        traffic = rec["hbm_bytes_per_launch"] if rec else None
+                        rec = json.load(open(tp)).get("%s:%s:%d" % (a.workload, pair_name, world)) or {}
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        flop = rec.get("fp64_flop_per_launch")
                     except Exception:
-                        traffic = None
+                        rec = {}
+                # SURVEY 8d asks for three numbers side by side: (1) compulsory-byte fraction of the HBM roofline, (2) the measured HBM
+                # rate (PMC bytes / launch time; a traffic measure), (3) FP64 FLOP / time / FP64-vector peak (what actually bounds it)
                 out["roofline"] = {"bound": "hbm", "kernel": pair_name, "achieved": alg / t_pair / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                    "frac": alg / t_pair / HBM_PEAK, "traffic": traffic,
                                    "algorithmic_bytes_per_launch": alg, "avg_launch_us": t_pair * 1e6,
-                                   "note": "fp64 pair kernel is FP64-ALU/LDS bound (about 100 FLOP per compulsory byte): see DESIGN.md"}
+                                   "measured_hbm_gbps": (traffic / t_pair / 1e9) if traffic else None,
+                                   "fp64_flop_per_launch": flop,
+                                   "fp64_tflops": (flop / t_pair / 1e12) if flop else None,
+                                   "fp64_frac": (flop / t_pair / FP64_VECTOR_PEAK) if flop else None,
+                                   "fp64_peak_tflops": FP64_VECTOR_PEAK / 1e12,
+                                   "counters_from": rec.get("round"),
+                                   "note": "fp64 pair kernel is FP64-ALU bound (about 100 FLOP per compulsory byte); fp64_flop_per_launch = "
+                                           "(2 FMA + ADD + MUL + TRANS) x 64 + 512 MFMA_MOPS from the SQ_INSTS_VALU_*_F64 counters in profiles/"}
+            # the streaming kernels: algorithmic bytes / launch time / HBM peak
+            n_local = n_atoms / world
+            stream = {}
+            for k, b in STREAM_BYTES_PER_ATOM.items():
+                if k in kern and kern[k]["calls"] > 0:
+                    bb = b + (32.0 if (k == "rank_gather" and case.get("tstat_type", 0) == 2) else 0.0)
+                    t_k = kern[k]["avg_us"] * 1e-6
+                    stream[k] = {"bytes_per_atom": bb, "avg_us": kern[k]["avg_us"], "gbps": bb * n_local / t_k / 1e9, "hbm_frac": bb * n_local / t_k / HBM_PEAK}
+            out["streaming"] = stream
         if world == 1 and not a.no_cpu_baseline:
             steps_cpu = a.cpu_steps or max(2, int(round(5.0e6 / n_atoms * 1.0)))   # ~3 us per atom-step -> about 15 s
             steps_cpu = min(steps_cpu, 200)

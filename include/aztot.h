@@ -192,6 +192,12 @@ int aztot_get_stats(aztot_md *md, aztot_stats *out);
 int aztot_species_crossings(aztot_md *md, int64_t *out, int cap);
 int aztot_md_to_host(aztot_md *md, aztot_state *out);
 int aztot_set_state(aztot_md *md, const aztot_state *in);
+/* the cell list as the device holds it after the last sort: cudaMD::firstAtomInCell / cellIndexes (cuStruct.h:219-222;
+   calc_firstAtomInCell cuSort.cu:130-143, sort_atoms cuSort.cu:145-197).  dims[3] = cells per axis of this rank's window;
+   cell_start[c] = first slot of cell c = (ix * ny + iy) * nz + iz (n_cells + 1 entries, the last one = resident atoms);
+   atom_id[s] = original index of the atom in slot s.  Either array may be NULL; caps are entry counts.  Returns the number of
+   cells (or a negative error); never part of a step - a read-back for tests and restarts. */
+int aztot_cell_table(aztot_md *md, int32_t dims[3], int32_t *cell_start, int cap_cells, int32_t *atom_id, int cap_atoms);
 
 /* ---- measurement ------------------------------------------------------------------------------------ */
 /* per-kernel HIP-event times accumulated since the last reset (options.profile = 1).
@@ -208,6 +214,9 @@ int aztot_comm_make_id(void *id_bytes);
 /* diagnostic: brings up a ONE-rank RCCL communicator on `device` and runs the slab ring exchange with itself (both messages in
    the N-GPU call order) plus both all-reduce flavours; AZTOT_OK if RCCL is usable on this node and delivers what was sent */
 int aztot_comm_selftest(int device);
+/* number of ranks in the RCCL communicator that carries this handle's halo exchange (ncclCommCount); 0 when the handle does not
+   use RCCL (single GPU, host-staged callbacks, loopback).  Lets a launcher prove which transport a run really used. */
+int aztot_comm_ranks(aztot_md *md);
 /* host-staged exchange callback for tests without RCCL (gloo): send `sbytes` to `peer`, receive into rbuf */
 typedef int (*aztot_sendrecv_fn)(void *ctx, int send_peer, const void *sbuf, int64_t sbytes,
                                  int recv_peer, void *rbuf, int64_t rcap, int64_t *rbytes);

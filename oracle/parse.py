@@ -161,6 +161,7 @@ def parse_dir(directory, with_atoms=True):
     ns = len(species)
     vdw = [[None] * ns for _ in range(ns)]
     max_rvdw = 0.0
+    vdw_raw = []          # (specA, specB, type id, rc, parameters as written): the array entry points take input units
     nv = f.find(" vdw %d")
     for _ in range(nv or 0):
         a, b, c = f.next("s"), f.next("s"), f.next("s")
@@ -170,6 +171,7 @@ def parse_dir(directory, with_atoms=True):
         pp = prepare_vdw(t, rc, p)
         max_rvdw = max(max_rvdw, rc)
         ia, ib = names.index(a), names.index(b)
+        vdw_raw.append((ia, ib, t, rc, list(p)))
         vdw[ia][ib] = pp
         if t != 7:
             vdw[ib][ia] = pp
@@ -197,7 +199,7 @@ def parse_dir(directory, with_atoms=True):
             nm = f.next("s")
             sp = species[names.index(nm)]
             sp["radA"], sp["radB"], sp["mxEng"] = f.next("f"), f.next("f"), f.next("f")
-    out.update(species=species, vdw=vdw, n_vdw=nv or 0, max_rvdw=max_rvdw)
+    out.update(species=species, vdw=vdw, vdw_raw=vdw_raw, n_vdw=nv or 0, max_rvdw=max_rvdw)
 
     # ---- atoms.xyz
     a = Scanner(_read(os.path.join(directory, "atoms.xyz")))

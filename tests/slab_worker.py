@@ -67,6 +67,8 @@ def main():
     elif name.startswith("rand"):   # seeded random system (tests/util.py random_case), box stretched along x to fit the ranks
         from util import random_case
         case = random_case(int(name[4:]), x_cells=2 * world + 2)
+    elif name == "big":      # long enough along x for 8 slabs of >= 2 cell layers
+        case = inputs.lj_case((40, 5, 5), a=5.26, seed=13, rc=6.5, cell_list=6.5, vel_T=600.0)
     elif name == "hot":
         case = inputs.lj_case((14, 5, 5), a=5.4, seed=3, rc=7.0, cell_list=7.0, vel_T=4000.0)
     else:
@@ -102,7 +104,7 @@ def main():
         rs, rst = ref.state(), ref.stats()
         from util import rel_err
         errs = {k: rel_err(merged[k], rs[k]) for k in keys if np.abs(rs[k]).max() > 0}
-        out = {"world": world, "n_atoms": len(case["types"]), "owned_total": int(counts.item()),
+        out = {"world": world, "transport": transport, "rccl_ranks": eng.comm_ranks(), "n_atoms": len(case["types"]), "owned_total": int(counts.item()),
                "every_atom_owned_once": bool((cover.numpy() == 1).all()), "max_rel_err_vs_single": max(errs.values()), "errs": errs,
                "energy_rel": {k: abs(st[k] - rst[k]) / (abs(rst[k]) + 1e-300) for k in ("engTot", "engVdW", "engKin", "engCoul", "engTemp", "engBond", "engAngle", "engCoulRec", "engCoulConst") if abs(rst[k]) > 0},
                "cross": [st["negCross"], st["posCross"], rst["negCross"], rst["posCross"]],

@@ -1,0 +1,220 @@
+"""GPU parity at the sizes bench.py runs (BASELINE configs 3 and 4: 1 000 188 atoms, 74 088 cells) and on the reference's two
+shipped example inputs (configs 1 and 5), through the C ABI.
+
+At 1 M atoms the engine takes code paths no small test reaches: the multi-workgroup prefix sum (k_scan_totals + k_scan_apply, above
+16 384 cells; reference: calc_firstAtomInCell cuSort.cu:130-143), the deferred second half-kick (more than 262 144 atoms; reference:
+verlet_2stage cuMDfunc.cu:521-600 / integrate2 integrators.cpp:486-531) and the 8-XCD workgroup -> cell mapping on 74 088 workgroups.
+The checker is the reference's own serial code (oracle/_ref/ref_driver, main.cpp:89-142) when the binary travelled to this machine,
+else the oracle (bit-identical to it on every golden fixture).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from aztotmd_amd import api, inputs
+from oracle import oracle, parse
+from util import case_from_parsed, materialise_case_study, rel_err
+
+pytestmark = pytest.mark.gpu
+XVF = ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz")
+
+
+def cpu_steps(case, nsteps):
+    """(per-atom state, energies, who computed it) after `nsteps` from F = 0 on the serial CPU path."""
+    if oracle.ref_available():
+        c = dict(case)
+        c.update(nsteps=nsteps, dump=[nsteps], init_forces=0, use_clist=1, center_box=0)
+        d = oracle.run_ref(c, timeout=900)["dumps"][nsteps]
+        return d, {"engVdW": d["engVdW"], "engCoul": d["engElec3"], "engKin": d["engKin"], "engTot": d["engTot"]}, "reference binary"
+    o = oracle.Oracle(case)
+    o.step(nsteps)                       # forces start at 0, as on the reference's GPU path (sys_init.cpp:551-553)
+    st = o.stats()
+    return o.state(), {"engVdW": st["engVdW"], "engCoul": st["engElec3"], "engKin": st["engKin"], "engTot": st["engTot"]}, "oracle"
+
+
+def host_cell_table(s, box, dims):
+    """count_cell (cuSort.cu:114-128): cell = floor(x * cRevSize) per axis, in double; then the exclusive prefix sum."""
+    idx = []
+    for k, key in enumerate(("x", "y", "z")):
+        c = np.floor(s[key] * (dims[k] / box[k])).astype(np.int64) % dims[k]
+        idx.append(c)
+    cell = (idx[0] * dims[1] + idx[1]) * dims[2] + idx[2]
+    hist = np.bincount(cell, minlength=dims[0] * dims[1] * dims[2])
+    start = np.concatenate([[0], np.cumsum(hist)])
+    return cell, start
+
+
+def check_cell_table(e, s, box):
+    dims, start, ids = e.cell_table()
+    cell, ref_start = host_cell_table(s, box, dims)
+    assert np.array_equal(start, ref_start), "cell offsets differ from the host prefix sum"
+    assert np.array_equal(np.sort(ids), np.arange(len(ids))), "every atom sits in exactly one slot"
+    slot_cell = np.repeat(np.arange(len(start) - 1), np.diff(start))
+    assert np.array_equal(cell[ids], slot_cell), "an atom sits in a slot of the wrong cell"
+    same = slot_cell[1:] == slot_cell[:-1]
+    assert np.all(ids[1:][same] > ids[:-1][same]), "atoms of one cell are not in id order"
+    return dims
+
+
+@pytest.mark.parametrize("name", ["C4", "C3"])
+def test_full_size_steps_match_the_serial_cpu_path(name):
+    """BASELINE configs 4 and 3 at their full 1 000 188 atoms: 3 steps from F = 0, per-atom x / v / f to 1e-9 (north star), energies
+    to 1e-11, plus the device's cell table against a host prefix sum."""
+    case = inputs.config(name)
+    n = len(case["types"])
+    assert n == 1000188
+    ref, eref, who = cpu_steps(case, 3)
+    e = api.Engine(api.Model.from_case(case), initial_forces=0)
+    e.step(3)
+    s, st = e.state(), e.stats()
+    assert st["n_cells"] == 42 ** 3 and st["n_cells"] > 16384           # the multi-workgroup scan is the one that ran
+    for k in XVF:
+        assert rel_err(s[k], ref[k]) < 1e-9, (name, who, k, rel_err(s[k], ref[k]))
+    for k in ("fx", "fy", "fz"):
+        assert rel_err(s[k], ref[k]) < 1e-11, (name, who, k, rel_err(s[k], ref[k]))
+    for k, v in eref.items():
+        assert abs(st[k] - v) <= 1e-11 * abs(v) + 1e-12, (name, who, k, st[k], v)
+    assert st["pairs_dropped"] == 0
+    for k in ("fx", "fy", "fz"):
+        assert abs(s[k].sum()) < 1e-8                                    # Newton 3 over 1 M atoms
+    check_cell_table(e, s, case["box"])
+    # the deferred half-kick path must give the same trajectory as k_integrate2 every step (debug bit 128), bit for bit
+    e2 = api.Engine(api.Model.from_case(case), initial_forces=0, debug=128, use_graph=0)
+    e2.step(3)
+    s2 = e2.state()
+    for k in XVF:
+        assert np.array_equal(s[k], s2[k]), k
+    e2.close()
+    # and more steps, graph-replayed in pairs, still agree with eager launches
+    e.step(5)
+    e3 = api.Engine(api.Model.from_case(case), initial_forces=0, use_graph=0)
+    e3.step(8)
+    s, s3 = e.state(), e3.state()
+    for k in ("x", "vx", "fx"):
+        assert np.array_equal(s[k], s3[k]), k
+
+
+@pytest.mark.parametrize("cell", [2.2, 3.1])
+def test_multi_workgroup_scan_on_a_fine_grid(cell):
+    """40 000 atoms (BASELINE config 2) on 2.2 A / 3.1 A cells: 52 x 52 x 65 = 175 760 cells, most of them empty - k_scan_totals +
+    k_scan_apply (172 chunks) against the host prefix sum, forces against the oracle."""
+    case = inputs.config("C2")
+    e = api.Engine(api.Model.from_case(case), cell_size=cell)
+    s, st = e.state(), e.stats()
+    assert st["n_cells"] > 16384
+    dims = check_cell_table(e, s, case["box"])
+    assert dims[0] * dims[1] * dims[2] == st["n_cells"]
+    o = oracle.Oracle(case)
+    o.forces(1)
+    so = o.state()
+    for k in ("fx", "fy", "fz"):
+        assert rel_err(s[k], so[k]) < 1e-11, (k, rel_err(s[k], so[k]))
+    e.step(7)
+    s = e.state()
+    check_cell_table(e, s, case["box"])
+    o.step(7)
+    for k in XVF:
+        assert rel_err(s[k], o.state()[k]) < 1e-9, k
+
+
+def test_forces_call_leaves_wall_counters_alone():
+    """aztot_forces after aztot_step collects the energies only: wall momenta, crossing counts and dropped pairs of the previous
+    step window must not be added a second time (k_finalize)."""
+    case = inputs.lj_case((5, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5, vel_T=3000.0)
+    e = api.Engine(api.Model.from_case(case))
+    e.step(40)
+    a = e.stats()
+    assert sum(a["posCross"]) + sum(a["negCross"]) > 20
+    e.forces()
+    b = e.stats()
+    for k in ("posCross", "negCross", "posMom", "negMom", "pairs_dropped"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    e.forces()
+    e.step(25)
+    c = e.stats()
+    o = oracle.Oracle(case)
+    o.forces(1)
+    o.step(65)
+    so = o.stats()
+    assert c["negCross"] + c["posCross"] == [so["cross"][k] for k in (0, 2, 4, 1, 3, 5)]
+    mom = [so["momXn"], so["momYn"], so["momZn"], so["momXp"], so["momYp"], so["momZp"]]
+    assert rel_err(c["negMom"] + c["posMom"], mom) < 1e-9
+
+
+def test_set_state_after_graph_replay_keeps_thermostat_state_attached():
+    """U / radius set AFTER the step graph was captured: the sort must start carrying them (the captured graph had the old
+    carry mode baked in and is rebuilt)."""
+    case = inputs.lj_case((6, 6, 6), a=5.3, seed=17, rc=7.0, cell_list=7.0, vel_T=600.0)
+    n = len(case["types"])
+    e = api.Engine(api.Model.from_case(case), use_graph=1)
+    e.step(6)                                    # captures + replays
+    U = np.arange(n, dtype=float) + 0.25
+    rad = 2.0 + np.arange(n, dtype=float) / n
+    e.set_state(U=U, radius=rad)
+    e.step(40)                                   # atoms change cells: a stale graph would scramble U against the ids
+    s = e.state()
+    assert np.array_equal(s["U"], U) and np.array_equal(s["radius"], rad)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's shipped example inputs, read by aztot_init_md from the four files
+# ---------------------------------------------------------------------------------------------------
+def test_case_study_1_through_the_hip_path(tmp_path):
+    """BASELINE config 1 verbatim: 40 000 Ar in a 1141.5 A box, 'temperature 298 radi', 'cell_list 85', 'elec fenn' demoted to none
+    (no charged species).  20 steps against the oracle: forces are exactly 0 (no pair inside 4 A), the thermostat moves v, U, radius."""
+    d = materialise_case_study(1, str(tmp_path / "cs1"), nstep=20)
+    m = api.Model.from_dir(d)
+    assert int(m.query("n_atoms")[0]) == 40000 and int(m.query("tstat_type")[0]) == 2 and int(m.query("elec_type")[0]) == 0
+    e = api.Engine(m)
+    case = case_from_parsed(parse.parse_dir(d))
+    o = oracle.Oracle(case)
+    o.forces(1)
+    s0 = e.state()
+    assert np.array_equal(s0["radius"], o.state()["rad"])               # initial radii: same table, same draw per atom id
+    e.step(20)
+    o.step(20)
+    s, so, st, sto = e.state(), o.state(), e.stats(), o.stats()
+    assert st["n_cells"] == 13 ** 3
+    assert all(np.all(s[k] == 0.0) for k in ("fx", "fy", "fz")) and st["engVdW"] == 0.0
+    for k in ("x", "y", "z", "vx", "vy", "vz"):
+        assert rel_err(s[k], so[k]) < 1e-9, (k, rel_err(s[k], so[k]))
+    assert rel_err(s["U"], so["U"]) < 1e-9 and rel_err(s["radius"], so["rad"]) < 1e-12
+    for a, b in (("engKin", "engKin"), ("engTemp", "engTemp"), ("engTot", "engTot")):
+        assert abs(st[a] - sto[b]) <= 1e-10 * abs(sto[b]), (a, st[a], sto[b])
+    assert st["negCross"] + st["posCross"] == [sto["cross"][k] for k in (0, 2, 4, 1, 3, 5)]
+
+
+def test_case_study_2_through_the_hip_path(tmp_path):
+    """BASELINE config 5 verbatim: 4 000 atoms, radius-dependent 'surk' potential rc 6.0 on 2.7 A cells (12^3 cells of 2.92 A, 7^3
+    stencil), radiative thermostat at 500 K + equilibration rescaling.  The radii the thermostat writes feed the next step's forces."""
+    d = materialise_case_study(2, str(tmp_path / "cs2"), nstep=30)
+    m = api.Model.from_dir(d)
+    e = api.Engine(m)
+    p = parse.parse_dir(d)
+    assert p["vdw"][0][0]["type"] == 7 and p["cell_list"] == 2.7
+    case = case_from_parsed(p)
+    case["freqEq"] = 5                      # the file's eqfreq 2500 would never fire in a 30-step test ...
+    case["nEq"] = 20
+    e.close()
+    e = api.Engine(api.Model.from_case(case))          # ... so the schedule is shortened; everything else is the file's
+    o = oracle.Oracle(case)
+    o.forces(1)
+    s, so = e.state(), o.state()
+    for k in ("fx", "fy", "fz"):
+        assert rel_err(s[k], so[k]) < 1e-11, k
+    assert e.stats()["n_cells"] == 12 ** 3
+    e.step(30)
+    o.step(30)
+    s, so, st, sto = e.state(), o.state(), e.stats(), o.stats()
+    for k in XVF:
+        assert rel_err(s[k], so[k]) < 1e-8, (k, rel_err(s[k], so[k]))
+    assert rel_err(s["U"], so["U"]) < 1e-8 and rel_err(s["radius"], so["rad"]) < 1e-9
+    for a, b in (("engVdW", "engVdW"), ("engKin", "engKin"), ("engTemp", "engTemp"), ("engTot", "engTot")):
+        assert abs(st[a] - sto[b]) <= 1e-9 * abs(sto[b]) + 1e-10, (a, st[a], sto[b])
+    # the files themselves (eqfreq 2500 untouched) run too and agree with the array entry point for the first steps
+    e1 = api.Engine(m)
+    e2 = api.Engine(api.Model.from_case(case_from_parsed(p)))
+    e1.step(12); e2.step(12)
+    for k in ("x", "vx", "fx", "U", "radius"):
+        assert np.array_equal(e1.state()[k], e2.state()[k]), k

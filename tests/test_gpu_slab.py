@@ -11,15 +11,26 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_ranks(nranks, name, nsteps, extra=None, port=29611):
+def transport_for(nranks):
+    """RCCL (ncclSend/ncclRecv over xGMI, RcclExchanger::exchange) whenever every rank can have a GPU of its own; the host-staged
+    gloo callback transport when the ranks have to share the one GPU of the development box (two RCCL ranks cannot share a device).
+    torch.cuda.device_count() does not initialise the GPU, and the workers are fresh torchrun children."""
+    import torch
+    return "rccl" if torch.cuda.device_count() >= nranks else "callback"
+
+
+def run_ranks(nranks, name, nsteps, extra=None, port=29611, transport=None):
+    transport = transport or transport_for(nranks)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(HERE, "slab_worker.py"), name, str(nsteps), "callback", json.dumps(extra or {})]
+           "--master-port", str(port), os.path.join(HERE, "slab_worker.py"), name, str(nsteps), transport, json.dumps(extra or {})]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("SLAB_RESULT ")]
     assert r.returncode == 0 and lines, (r.stdout[-3000:], r.stderr[-3000:])
-    return json.loads(lines[-1][len("SLAB_RESULT "):])
+    out = json.loads(lines[-1][len("SLAB_RESULT "):])
+    assert out["transport"] == transport
+    return out
 
 
 @pytest.mark.parametrize("nranks,name,nsteps,port", [(2, "lj", 40, 29611), (3, "fennel", 25, 29612), (4, "hot", 60, 29613), (2, "thermo", 20, 29614), (2, "nose", 15, 29616),
@@ -71,3 +82,17 @@ def test_rccl_library_selftest():
     N-GPU order, ncclAllReduce on the engine stream) on a one-rank communicator: the only way to run them on a one-GPU box."""
     from aztotmd_amd import api
     api.rccl_selftest(0)
+
+
+@pytest.mark.parametrize("nranks,name,nsteps", [(2, "lj", 40), (2, "mol", 40), (4, "hot", 60), (8, "big", 30)])
+def test_slabs_over_rccl(nranks, name, nsteps):
+    """The production transport between real devices: one process per GPU, ncclSend/ncclRecv ring exchange + ncclAllReduce.  Needs
+    as many GPUs as ranks (skipped on the one-GPU development box; runs as soon as the suite meets a multi-GPU node)."""
+    import torch
+    if torch.cuda.device_count() < nranks:
+        pytest.skip("needs %d GPUs, this machine has %d" % (nranks, torch.cuda.device_count()))
+    out = run_ranks(nranks, name, nsteps, port=29700 + nranks, transport="rccl")
+    assert out["rccl_ranks"] == nranks
+    assert out["every_atom_owned_once"] and out["owned_total"] == out["n_atoms"]
+    assert out["max_rel_err_vs_single"] < 1e-9, out["errs"]
+    assert all(v < 1e-10 for v in out["energy_rel"].values()), out["energy_rel"]

@@ -1,0 +1,155 @@
+"""Statistical / conservation invariants of the radiative thermostat (tstat_radi9 cuTemp.cu:689-773, adsorb_rand_photon :484-507,
+radiate_photon3 :631-685, radius law :757-759) on 40 000 atoms, through the C ABI.
+
+The reference has no CPU implementation of this thermostat, so parity with the *reference* cannot be pinned; what its
+physics does support is checked here without the oracle:
+  * energy ledger: every absorption adds exactly the photon's energy to (U + E_kin) of the atom, every emission removes exactly
+    radFrac * U - so the run's total (sum U + E_kin + E_pot) moves by (absorbed - radiated), with the absorbed part known from the
+    photon table and the radiated part bounded by the U's seen at the step boundaries;
+  * plateau: U_end(s) = (1 - 0.9) (U_end(s-1) + photon) up to the recoil energy  =>  <U> -> <photon> / 9 after a few steps, with
+    <photon> the mean of the Gamma(5, kT) table (5 kT up to the table's bisection tolerance);
+  * radius law: radius = radA / (radB - min(U, mxEng)) for every atom, inside [radA / radB, radA / (radB - mxEng)];
+  * seed independence of the averages (and seed dependence of the individual draws); isotropy of the recoil.
+"""
+import numpy as np
+import pytest
+
+from aztotmd_amd import api, inputs
+
+pytestmark = pytest.mark.gpu
+KB = 1.3806488E-23 / 1.60217733E-19
+MSC = 1.6605402E-27 / (1.60217733E-19 * 1e-24 / 1e-20)
+RADII = (2.73, 4.731, 0.2)            # 'radii Ar 2.73 4.731 0.2' of the shipped case studies
+REV_LIGHT, RAD_FRAC = 3.33567e-5, 0.9
+
+
+def gas(T=298.0, seed_pos=20240506, vel_T=298.0):
+    """40 000 Ar on a jittered 35^3 lattice in the 1141.5 A box of case study 1: no pair inside the 4 A cut-off, so the only thing
+    that changes velocities is the thermostat."""
+    c = inputs.config("C1")
+    c.update(T=T, tstat_type=2, radii=[RADII])
+    if vel_T:
+        rng = np.random.Generator(np.random.PCG64(99))
+        m = 39.9 * MSC
+        v = rng.normal(0.0, np.sqrt(KB * vel_T / m), size=(len(c["types"]), 3))
+        v -= v.mean(axis=0)
+        c.update(vx=v[:, 0].copy(), vy=v[:, 1].copy(), vz=v[:, 2].copy())
+    return c
+
+
+def kin(s, m):
+    return 0.5 * m * (s["vx"] ** 2 + s["vy"] ** 2 + s["vz"] ** 2)
+
+
+def test_per_atom_energy_ledger_and_plateau_in_a_force_free_gas():
+    case = gas()
+    N = len(case["types"])
+    m = 39.9 * MSC
+    model = api.Model.from_case(case)
+    ph = model.query("photons", seed=12345)
+    assert len(ph) == N and 4.5 * KB * 298.0 < ph.mean() < 5.5 * KB * 298.0       # Gamma(5, kT): mean 5 kT (temperature.cpp:28-89)
+    e = api.Engine(model, seed=12345)
+    prev = e.state()
+    assert np.all(prev["fx"] == 0.0) and np.all(prev["U"] == 0.0)
+    vmax = np.sqrt((prev["vx"] ** 2 + prev["vy"] ** 2 + prev["vz"] ** 2).max())
+    ids = np.arange(N)
+    meanU = []
+    for step in range(1, 13):
+        e.step(1)
+        cur = e.state()
+        assert np.all(cur["fx"] == 0.0)
+        pe = ph[(ids + step) % N]                                   # the photon atom `id` absorbs in step `step`
+        d_abs = pe * REV_LIGHT / m                                  # velocity kick of the absorption
+        # ledger per atom: (U + K)_after = (U + K)_before + photon - radiated, radiated = radFrac * U_mid >= 0
+        radiated = (prev["U"] + kin(prev, m)) + pe - (cur["U"] + kin(cur, m))
+        u_mid = prev["U"] + pe                                      # up to the absorption's recoil energy |dK| <= m v dv + m dv^2 / 2
+        slack = m * (vmax + 1.0) * d_abs + 0.5 * m * d_abs ** 2
+        assert np.all(u_mid > 2e-4)                                 # every atom is above the emission threshold (cuTemp.cu:747)
+        assert np.all(np.abs(radiated - RAD_FRAC * u_mid) <= RAD_FRAC * slack + 1e-15), np.abs(radiated - RAD_FRAC * u_mid).max()
+        # what is left: U_after = U_mid - radiated - recoil of the emission (|dK| <= m v dv' + ..., dv' = radiated * revLight / m)
+        d_rad = radiated * REV_LIGHT / m
+        slack2 = slack + m * (vmax + 1.0) * d_rad + 0.5 * m * d_rad ** 2
+        assert np.all(np.abs(cur["U"] - (u_mid - radiated)) <= slack2 + 1e-15)
+        # radius law (cuTemp.cu:757-759)
+        want = RADII[0] / (RADII[1] - np.minimum(cur["U"], RADII[2]))
+        assert np.abs(cur["radius"] - want).max() < 1e-15
+        assert cur["radius"].min() >= RADII[0] / RADII[1] - 1e-15 and cur["radius"].max() <= RADII[0] / (RADII[1] - RADII[2]) + 1e-15
+        st = e.stats()
+        assert abs(st["engTemp"] - cur["U"].sum()) < 1e-10 * cur["U"].sum()
+        assert abs(st["engKin"] - kin(cur, m).sum()) < 1e-11 * st["engKin"]
+        meanU.append(cur["U"].mean())
+        prev = cur
+    # plateau: <U> -> <photon> (1 - f) / f, reached geometrically (ratio 0.1 per step)
+    target = ph.mean() * (1.0 - RAD_FRAC) / RAD_FRAC
+    assert abs(meanU[-1] - target) < 0.01 * target, (meanU[-1], target)
+    assert abs(meanU[0] - 0.1 * ph.mean()) < 0.01 * ph.mean()
+    # recoil is isotropic: the net momentum picked up stays within a random walk of 2 kicks per atom per step
+    p = np.array([cur[k].sum() for k in ("vx", "vy", "vz")]) * m
+    kick = m * (ph.mean() * REV_LIGHT / m)
+    assert np.abs(p).max() < 6.0 * kick * np.sqrt(2 * 12 * N / 3.0)
+
+
+def test_total_energy_ledger_in_a_dense_liquid():
+    """C2 (40 000 Ar, liquid density, LJ rc 8.5) with the thermostat on: E_tot + sum(U) changes per step by absorbed - radiated, where
+    absorbed is the photon table's sum over atoms and radiated = radFrac * sum(U_mid) up to the recoil energies."""
+    case = inputs.config("C2")
+    case.update(T=85.0, tstat_type=2, radii=[RADII])
+    N = len(case["types"])
+    m = 39.9 * MSC
+    model = api.Model.from_case(case)
+    ph = model.query("photons", seed=777)
+    e = api.Engine(model, seed=777)
+    e.step(10)                                   # past the transient of U
+    a = e.stats()
+    Ua = e.state()["U"]
+    for step in range(11, 16):
+        e.step(1)
+        b = e.stats()
+        Ub = e.state()["U"]
+        absorbed = ph.sum()                      # every atom absorbs one photon per step; the index shift only permutes the table
+        led_a = a["engTot"] + a["engTemp"]       # engTot = kinetic + potential (integrators.cpp:70-71); engTemp = sum U
+        led_b = b["engTot"] + b["engTemp"]
+        radiated = led_a + absorbed - led_b
+        est = RAD_FRAC * (Ua.sum() + absorbed)
+        # slack: recoil energies (m v dv per event, both signs) + the Verlet integrator's own energy error over one step
+        assert abs(radiated - est) < 5e-4 * est, (step, radiated, est)
+        a, Ua = b, Ub
+    target = ph.mean() * (1.0 - RAD_FRAC) / RAD_FRAC
+    assert abs(Ub.mean() - target) < 0.01 * target
+
+
+def test_averages_do_not_depend_on_the_seed_but_draws_do():
+    case = gas(vel_T=120.0)
+    m = 39.9 * MSC
+    res = []
+    for seed in (1, 2, 12345):
+        e = api.Engine(api.Model.from_case(case), seed=seed)
+        e.step(15)
+        s = e.state()
+        res.append((s["U"].mean(), kin(s, m).mean(), s["vx"].copy(), s["radius"].mean()))
+    for k in (1, 2):
+        assert abs(res[k][0] - res[0][0]) < 0.02 * res[0][0]                 # <U>: 40 000 independent Gamma draws -> ~0.3 % scatter
+        assert abs(res[k][1] - res[0][1]) < 1e-3 * res[0][1]                 # <E_kin> barely moves in 15 steps, the same for every seed
+        assert abs(res[k][3] - res[0][3]) < 1e-4 * res[0][3]
+        assert not np.array_equal(res[k][2], res[0][2])                      # the recoil directions themselves differ
+    # same seed -> same run, bit for bit (counter-based RNG keyed by seed, step, atom id, draw)
+    e = api.Engine(api.Model.from_case(case), seed=12345)
+    e.step(7); e.step(8)
+    assert np.array_equal(e.state()["vx"], res[2][2])
+
+
+def test_thermostat_heats_a_cold_gas_and_cools_a_hot_one():
+    """direction of the energy flow (the one property a thermostat must have): recoil kicks heat a gas at rest; a gas far above the
+    bath temperature loses kinetic energy on average because emission is aimed against the velocity (radiate_photon3 cuTemp.cu:631-685:
+    cos(phi) drawn from [-1, -ermc/v])."""
+    m = 39.9 * MSC
+    cold = api.Engine(api.Model.from_case(gas(vel_T=None)))
+    cold.step(30)
+    assert cold.stats()["engKin"] > 0.0
+    k1 = cold.stats()["engKin"]
+    cold.step(30)
+    assert cold.stats()["engKin"] > k1
+    hot = api.Engine(api.Model.from_case(gas(T=298.0, vel_T=30000.0)))
+    k0 = hot.stats()["engKin"] if hot.stats()["engKin"] > 0 else kin(hot.state(), m).sum()
+    hot.step(60)
+    assert hot.stats()["engKin"] < k0

@@ -153,3 +153,38 @@ def add_random_dynamics(case, seed):
             if angles:
                 case.update(angle_types=angle_types, angles=np.array(angles, dtype=np.int32))
     return case
+
+
+def materialise_case_study(k, directory, nstep=None):
+    """Write the reference's shipped example input k (1 or 2) - stored as data in tests/golden/case_study_k.npz by
+    tests/golden/make_case_studies.py - back into `directory` as atoms.xyz / field.txt / control.txt / cuda.txt."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "case_study_%d.npz" % k))
+    os.makedirs(directory, exist_ok=True)
+    names, idx, pos = [str(s) for s in z["names"]], z["name_idx"], z["pos"]
+    eol = "\r\n" if bool(z["crlf"]) else "\n"           # the shipped files have DOS line ends: kept, the parser must cope
+    with open(os.path.join(directory, "atoms.xyz"), "w", newline="") as f:
+        f.write("%d%s%s%s" % (int(z["n"]), eol, bytes(z["box_line"]).decode(), eol))
+        f.writelines("%s\t%f\t%f\t%f%s" % (names[idx[i]], pos[i, 0], pos[i, 1], pos[i, 2], eol) for i in range(len(pos)))
+    for fn in ("field.txt", "control.txt", "cuda.txt"):
+        data = bytes(z[fn.replace(".", "_")])
+        if fn == "control.txt" and nstep is not None:
+            import re
+            data = re.sub(rb"nstep\s+\d+", b"nstep %d" % nstep, data, count=1)
+        with open(os.path.join(directory, fn), "wb") as f:
+            f.write(data)
+    return directory
+
+
+def case_from_parsed(o, seed=12345):
+    """oracle/parse.py's view of an input directory as the `case` dict the oracle (and aztot_model_create) take."""
+    N = o["n_atoms"]
+    sp = o["species"]
+    return {"box": list(o["box"]), "dt": o["dt"], "nsteps": 0, "species": [(s["mass_amu"], s["charge"]) for s in sp],
+            "names": [s["name"] for s in sp], "vdw": [tuple(v) for v in o["vdw_raw"]], "types": np.asarray(o["types"], dtype=np.int32),
+            "x": np.asarray(o["x"], dtype=float), "y": np.asarray(o["y"], dtype=float), "z": np.asarray(o["z"], dtype=float),
+            "vx": np.zeros(N), "vy": np.zeros(N), "vz": np.zeros(N), "elec_type": o["elec_type"], "rReal": o["r_real"] if o["elec_type"] else 0.0,
+            "alpha": o["alpha"] if o["elec_type"] else 0.0, "T": o["temperature"], "tstat_type": o["tstat_type"], "tau": o["tau"],
+            "nEq": o["nequil"], "freqEq": o["eqfreq"] or 1, "use_clist": o["use_cell_list"], "cell_list": o["cell_list"],
+            "radii": [(s["radA"], s["radB"], s["mxEng"]) for s in sp], "frozen": [s["frozen"] for s in sp], "seed": seed,
+            "Ux": o["elecfield"][0], "Uy": o["elecfield"][1], "Uz": o["elecfield"][2], "center_box": 0, "init_forces": 1}

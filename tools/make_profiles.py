@@ -40,12 +40,25 @@ with open(os.path.join(P, "%s_rocprofv3_pmc_hbm_traffic.csv" % tag), "w", newlin
     wri = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     wri.writeheader()
     wri.writerows(rows)
+# FP64 work per launch from the SQ instruction counters (optional 5th pass of tools/profile_run.sh): wave-instructions x 64 lanes,
+# FMA counted twice; MFMA_MOPS in units of 512 FLOP (counter_defs.yaml: TOTAL_64_OPS)
+fp64_dir = os.path.join(os.path.dirname(fetch_dir.rstrip("/")), "fp64")
+flop = {}
+if os.path.isdir(fp64_dir):
+    c = {n: means(fp64_dir, "SQ_INSTS_VALU_%s_F64" % n) for n in ("FMA", "ADD", "MUL", "TRANS", "MFMA_MOPS")}
+    for k in set().union(*[set(v) for v in c.values()]):
+        g = lambda n: c[n].get(k, (0.0, 0))[0]
+        flop[k] = (2.0 * g("FMA") + g("ADD") + g("MUL") + g("TRANS")) * 64.0 + 512.0 * g("MFMA_MOPS")
+    for f in ("sq_summary.txt", "fp64_summary.txt"):
+        src = os.path.join(os.path.dirname(fp64_dir), f)
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(P, "%s_rocprofv3_pmc_%s" % (tag, f.replace("_summary", "_counters"))))
 tp = os.path.join(P, "pmc_traffic.json")
 rec = json.load(open(tp)) if os.path.exists(tp) else {}
 for r in rows:
     name = "pair_tile" if r["kernel"].startswith("k_pair_tile<") else ("pair_atom" if r["kernel"] == "k_pair_atom" else None)
     if name:
-        rec["%s:%s:%d" % (workload, name, ngpu)] = {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"], "round": tag, "kernel": r["kernel"],
+        rec["%s:%s:%d" % (workload, name, ngpu)] = {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"], "fp64_flop_per_launch": flop.get(r["kernel"]), "round": tag, "kernel": r["kernel"],
                                                     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH doubled per MI355X_MICROARCH.md"}
 json.dump(rec, open(tp, "w"), indent=1)
 print(open(os.path.join(P, "%s_rocprofv3_pmc_hbm_traffic.csv" % tag)).read())
