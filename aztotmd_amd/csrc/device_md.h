@@ -113,6 +113,7 @@ struct StepParams
     int32_t rank, nranks;
     int32_t fuseKick;             // 1: the pair kernel also applies the second half-kick and books the kinetic energy (plain NVE steps)
     int32_t vdwFamily;            // pad1 == 2: the one potential type all defined species pairs share (1 lnjs, 2 buck, 3 p746, 4 bmhs)
+    double ljDropR2;              // single_lj: r^2 beyond which |f| <= 1e5 is certain, so the 'pair dropped' rule (integrators.cpp:170) need not be evaluated
 };
 
 // reduction slots of the per-block partial buffer (deterministic two-stage sums)

@@ -160,6 +160,15 @@ void Engine::construct()
     P_.use_radii = 0;
     for (const auto& p : m.pairpots) if (p.type && p.use_radii) P_.use_radii = 1;
     P_.single_lj = (m.nSpec() == 1 && m.pairpots[0].type == AZTOT_VDW_LJ && m.elec_type == AZTOT_ELEC_NONE) ? 1 : 0;
+    P_.ljDropR2 = 1e300;
+    if (P_.single_lj)
+    {   // fer_lj (vdw.cpp:16-26): f = p2 s^3 (2 s^3 - 1) / r^2 with s = p1 / r^2 (p1 = sigma^2, p2 = 24 eps).  For s >= 1: |f| <= 3 p2 s^7 / p1,
+        // so |f| <= 1e5 whenever s^7 <= 1e5 p1 / (3 p2); for s < 1: |f| < p2 / p1.  The kernel evaluates the exact f^2 > 1e10 rule only when
+        // some pair of the wave is inside TWICE that r^2 (a liquid never is).
+        const PairPot& lj = m.pairpots[0];
+        const double ratio = 3.0 * lj.p2 / (1e5 * lj.p1);
+        if (ratio > 0.0 && ratio < 1.0 && lj.p2 / lj.p1 < 1e5) P_.ljDropR2 = 2.0 * lj.p1 * std::pow(ratio, 1.0 / 7.0);
+    }
     {   // kernel specialisation 2/3: few species, ONE potential family among lnjs / buck / p746 / bmhs for every defined pair, no
         // radius-dependent potential, electrostatics none / direct / Fennell / Ewald inside the domain of the erfcx fit
         int family = 0;

@@ -740,8 +740,13 @@ __global__ void k_scale_decision(StepParams P, DevStats* st, const double* __res
 //   tstat_radi9 cuTemp.cu:689-773, adsorb_rand_photon :484-507, radiate_photon3 :631-685,
 //   get_angled_vector :395-453 - fp64, counter-based RNG, fixes of SURVEY Appendix C-9..C-12.
 // ------------------------------------------------------------------------------------------------
+// The construction of the basis (v2, v3) around v is ill-conditioned when |v_x| << |v|: v2.x = -(v1.y + v1.z) / v1.x amplifies the last-bit
+// noise of v1 by 1 / |v1.x| (the preset unit vectors contain such directions, e.g. (2e-13, 0.7071, -0.7071), and the first emission of an
+// atom at rest is aimed along one of them).  No FMA contraction here, so that the same v gives the same basis, bit for bit, as the
+// scalar C arithmetic of the CPU restatement; both bases are equally valid physically (the azimuth is uniformly random).
 __device__ __forceinline__ void angled_vector(const double v[3], double cos_phi, double theta, double out[3])
 {
+#pragma clang fp contract(off)
     const double l1 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     double v1[3] = {v[0] / l1, v[1] / l1, v[2] / l1}, v2[3], v3[3];
     if (v1[0] != 0.0) { v2[1] = 1.0; v2[2] = 1.0; v2[0] = -(v1[1] * v2[1] + v1[2] * v2[2]) / v1[0]; }

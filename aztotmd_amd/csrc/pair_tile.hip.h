@@ -22,7 +22,15 @@ namespace aztot {
 
 constexpr int kTileCap = 320;      // candidates resident in LDS per wave
 constexpr int kTilePad = 16;       // far-away dummies behind the last candidate (4 unrolled iterations x 4 slices)
-constexpr int kTileLds = kTileCap + kTilePad;
+constexpr int kTileLds = kTileCap + kTilePad;     // = 16 (mod 32): the three coordinate arrays start 32 banks apart, so the 16 + 16 (+ 16) lanes of
+                                                  // the matrix-operand read below hit 64 different banks
+static_assert(kTileLds % 32 == 16, "coordinate arrays must be staggered by half the LDS banks");
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// where -|r|^2 of tile entry p lives: inside every block of 16 the order is transposed (entry s + 4 r at 4 s + r), so that the four
+// candidates a lane owns in a block (slice s: s, s + 4, s + 8, s + 12) are one aligned 16-byte read
+__device__ __forceinline__ int tw_slot(int p) { return (p & ~15) | ((p & 3) << 2) | ((p >> 2) & 3); }
 
 // the tile kernel needs every neighbour cell to be reached through exactly one periodic image
 inline bool pair_tile_supported(const StepParams& P)
@@ -72,14 +80,16 @@ constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-
 
 template <int MODE, int VDW, int LG>
 __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots, const DevPot& lj,
-                                            const double* tx, const double* ty, const double* tz, const uint8_t* ttyp, const double* trad,
+                                            const double* tx, const double* ty, const double* tz, const float* tw, const uint8_t* ttyp, const double* trad,
                                             const double* pairTab, int T, int slice, double xi, double yi, double zi, int ti, double radi,
-                                            PairAcc& acc)
+                                            float filtB, float filtC, PairAcc& acc)
 {
     constexpr int NS = kWave >> LG;
     const int iters = ((T + NS - 1) / NS + 3) & ~3;        // per-lane candidates, rounded up to the unroll factor
     const double r2Filter = P.r2Max * (1.0 + 1e-13);       // conservative pass-1 threshold (see below)
+    const double ljDropR2 = P.ljDropR2;                   // MODE 1: no pair beyond this r^2 can break the f^2 > 1e10 rule (Engine::construct)
     int nDropHalf = 0;
+    if (P.pad0 & 2048) return;                             // measurement aid (bench.py --debug 2048): staging only, forces are wrong
     for (int rb = 0; rb < iters; rb += 96)
     {
         uint32_t m[3];
@@ -89,6 +99,40 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
             const int tb = rb + w * 32;
             const int nb = min(32, iters - tb);            // multiple of 4, may be <= 0
             uint32_t miss = 0xFFFFFFFFu;                   // one bit per candidate, 1 = outside the cut-off
+            if (LG == 4)
+            {   // 16 atoms x 4 slices: the distance filter of a block of 16 candidates x 16 atoms is ONE v_mfma_f32_16x16x4_f32:
+                //   D[cand][atom] = -|rj|^2 + (xj, yj, zj, 1) . (2 xi, 2 yi, 2 zi, thr - |ri|^2) = thr - |ri - rj|^2
+                // in f32 on cell-relative coordinates (|x| < cell/2 + rc), thr widened by the f32 error bound, so the filter stays
+                // conservative; pass 2 applies the exact fp64 test.  The matrix instruction holds the vector pipe for ~38 cycles per 256
+                // tests where the fp64 VALU form below needs ~140 (tools/ubench/valu_rates.hip); an fp64 MFMA would not help: it runs on
+                // the same fp64 units as v_fma_f64 (measured: additive).  Operand maps (gfx950): A[row l&15][k l>>4], B[k l>>4][col l&15],
+                // C/D[row 4 (l>>4) + reg][col l&15].  Rows are fed in the order perm(c) = (c >> 2) + 4 (c & 3), which makes register r of the
+                // lane (atom l&15, slice l>>4) the candidate 16 B + slice + 4 r: exactly the lane's own interleaved candidates; the
+                // -|rj|^2 of those four candidates arrive as the C operand through one 16-byte LDS read (tw is stored in that order).
+                const int lane = threadIdx.x;
+                const int c = lane & 15, k = lane >> 4;
+                const int permc = (c >> 2) + ((c & 3) << 2);
+                // lanes k = 3 feed the constant 1; they read (and ignore) the y array: banks 32-63, away from the z lanes of their half-wave
+                const double* pa = tx + (k == 3 ? 1 : k) * kTileLds + tb * NS + permc;
+                const float4_t* pc = (const float4_t*)(tw + tb * NS + 4 * k);
+                const int nblk = nb >> 2;                  // blocks of 16 candidates in this word (<= 8)
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                {
+                    if (q < nblk)
+                    {
+                        const float av = (float)pa[q * 16];
+                        const float a = (k == 3) ? 1.0f : av;
+                        const float4_t d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, filtB, pc[q * 4], 0, 0, 0);
+                        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[0]), 31);
+                        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[1]), 31);
+                        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[2]), 31);
+                        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[3]), 31);   // newest candidate in bit 0
+                    }
+                }
+                m[w] = (nb > 0) ? (~miss << (32 - nb)) : 0u;
+                continue;
+            }
             const double* px = &tx[tb * NS + slice];
             const double* py = &ty[tb * NS + slice];
             const double* pz = &tz[tb * NS + slice];
@@ -118,6 +162,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
         PairAcc rl = {0, 0, 0, 0, 0, 0};
         PairAcc& ra = (MODE == 1) ? rl : acc;              // measured: helps the LJ kernel (312 -> 309 us), hurts the Coulomb ones (629 -> 664)
         uint32_t cur = m[0], nxt = m[1], lst = m[2];
+        if (P.pad0 & 1024) { acc.eV += (double)(cur ^ nxt ^ lst); continue; }     // measurement aid (--debug 1024): no pass 2, forces are wrong
         int kbase = rb * NS + slice;                       // tile index of bit 31 of `cur`
         while (__any((cur | nxt | lst) != 0u))
         {
@@ -142,10 +187,15 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 const double sr2 = lj.p1 * r2i;
                 const double sr6 = sr2 * sr2 * sr2;
                 ra.eV = fma(0.5 * lj.p0, sr6 * (sr6 - 1.0), ra.eV);
-                const double f = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
-                const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
-                nDropHalf += __popcll(__ballot(tooBig));
-                const double fm = tooBig ? 0.0 : f;
+                double fm = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
+                // integrators.cpp:170-174: a pair with f^2 > 1e10 is dropped.  |f| grows monotonically as r shrinks below the minimum, so the
+                // exact test is only reached (wave-uniform branch, practically never) when some lane is inside a generous radius
+                if (__builtin_expect(__any(r2s < ljDropR2), 0))
+                {
+                    const bool tooBig = fm * fm > 1e10;
+                    nDropHalf += __popcll(__ballot(tooBig));
+                    fm = tooBig ? 0.0 : fm;
+                }
                 ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
             }
             else if (MODE >= 2)
@@ -246,7 +296,11 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks)
 {
-    __shared__ double tx[kTileLds], ty[kTileLds], tz[kTileLds];
+    __shared__ double txyz[3 * kTileLds];                            // candidate coordinates RELATIVE to the centre of the centre cell
+    __shared__ float tw[kTileLds];                                   // -(x^2 + y^2 + z^2) of the same, f32: 4th operand row of the filter
+    double* const tx = txyz;
+    double* const ty = txyz + kTileLds;
+    double* const tz = txyz + 2 * kTileLds;
     __shared__ uint8_t ttyp[MODE != 1 ? kTileLds : 1];               // species ids (< 16)
     __shared__ double trad[MODE == 0 ? kTileLds : 1];
     __shared__ double pairTab[MODE >= 2 ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
@@ -264,9 +318,16 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
         const int ncy = P.nc[1], ncz = P.nc[2];
         const int cz = cell % ncz, cy = (cell / ncz) % ncy, lx = cell / (ncy * ncz);
         const int ib = cellStart[cell], ie = cellStart[cell + 1];
-        // bounding box of the centre cell (global coordinates)
-        const double lo0 = (lx + P.cx0) * P.csz[0], lo1 = cy * P.csz[1], lo2 = cz * P.csz[2];
-        const double hi0 = lo0 + P.csz[0], hi1 = lo1 + P.csz[1], hi2 = lo2 + P.csz[2];
+        // centre of the centre cell (global coordinates) and its half edges: everything in the tile is relative to this point, which keeps
+        // the magnitudes small enough for the f32 distance filter and costs nothing in accuracy (differences of cell-relative fp64
+        // coordinates are exact or within one ulp of 16 A, below the ulp of a global coordinate in any box wider than 32 A)
+        const double h0 = 0.5 * P.csz[0], h1 = 0.5 * P.csz[1], h2 = 0.5 * P.csz[2];
+        const double cc0 = (lx + P.cx0) * P.csz[0] + h0, cc1 = cy * P.csz[1] + h1, cc2 = cz * P.csz[2] + h2;
+        // f32 filter threshold: rc^2 + error bound.  Operands are rounded to f32 (2^-24 relative), products and the 4-term sum are f32:
+        // |error| <= 2^-21 (|ri|^2 + |rj|^2 + 2 |ri.rj| + rc^2) with |r|^2 <= sum (h + rc)^2 - bounded here with a factor 4 to spare
+        const double rcut = sqrt(P.r2Max);
+        const double ext2 = (h0 + rcut) * (h0 + rcut) + (h1 + rcut) * (h1 + rcut) + (h2 + rcut) * (h2 + rcut);
+        const double filtThr = P.r2Max + 1.9073486328125e-06 * (4.0 * ext2 + P.r2Max);      // 2^-19
         const DevPot lj = pots[0];
         if (MODE >= 2)
         {
@@ -297,10 +358,15 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
             int ti = 0;
             if (validI)
             {
-                xi = A.x[myi]; yi = A.y[myi]; zi = A.z[myi];
+                xi = A.x[myi] - cc0; yi = A.y[myi] - cc1; zi = A.z[myi] - cc2;
                 if (MODE != 1) ti = A.type[myi];
                 if (MODE == 0 && P.use_radii) radi = A.rad[myi];
             }
+            // matrix-filter operand of this lane (used when the cell has <= 16 atoms): component `slice` of (2 xi, 2 yi, 2 zi, thr - |ri|^2).
+            // Idle atom slots sit at 1e30: their column of the filter is -inf ("outside") whatever the candidate
+            const float filtB = (slice == 0) ? (float)(2.0 * xi) : (slice == 1) ? (float)(2.0 * yi) : (slice == 2) ? (float)(2.0 * zi)
+                                                                                                    : (float)(filtThr - (xi * xi + yi * yi + zi * zi));
+            const float filtC = 0.0f;
             acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0; acc.eV = 0.0; acc.eC = 0.0; acc.dropped = 0.0;
             int T = 0;
 
@@ -314,14 +380,14 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                 // harmless candidate to chew on (uninitialised LDS could hold NaN patterns: 0 * NaN would poison a force)
                 if (lane < kTilePad)
                 {
-                    tx[T + lane] = -1e30; ty[T + lane] = 0.0; tz[T + lane] = 0.0;
+                    tx[T + lane] = -1e30; ty[T + lane] = 0.0; tz[T + lane] = 0.0; tw[tw_slot(T + lane)] = -3e38f;
                     if (MODE != 1) ttyp[T + lane] = 0;          // a valid species: the parameter table is indexed with it
                     if (MODE == 0) trad[T + lane] = 0.0;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (lg == 4) tile_passes<MODE, VDW, 4>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
-                else if (lg == 5) tile_passes<MODE, VDW, 5>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
-                else tile_passes<MODE, VDW, 6>(P, S, pots, lj, tx, ty, tz, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, acc);
+                if (lg == 4) tile_passes<MODE, VDW, 4>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
+                else if (lg == 5) tile_passes<MODE, VDW, 5>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
+                else tile_passes<MODE, VDW, 6>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
                 __builtin_amdgcn_wave_barrier();
                 T = 0;
             };
@@ -414,16 +480,18 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                                     yj += c1 == 0 ? -P.L[1] : (c1 == 2 ? P.L[1] : 0.0);
                                     zj += c2 == 0 ? -P.L[2] : (c2 == 2 ? P.L[2] : 0.0);
                                 }
+                                xj -= cc0; yj -= cc1; zj -= cc2;
                                 // distance from the centre cell's box: atoms farther than the cut-off cannot reach any atom in it
-                                const double bx = fmax(fmax(lo0 - xj, xj - hi0), 0.0);
-                                const double by = fmax(fmax(lo1 - yj, yj - hi1), 0.0);
-                                const double bz = fmax(fmax(lo2 - zj, zj - hi2), 0.0);
-                                const bool keep = (lane < gjn[u]) && (bx * bx + by * by + bz * bz) <= P.r2Max;
+                                const double bx = fmax(fabs(xj) - h0, 0.0);
+                                const double by = fmax(fabs(yj) - h1, 0.0);
+                                const double bz = fmax(fabs(zj) - h2, 0.0);
+                                const bool keep = (lane < gjn[u]) && (bx * bx + by * by + bz * bz) <= P.r2Max * (1.0 + 1e-12);
                                 const unsigned long long mask = __ballot(keep);
                                 if (keep)
                                 {
                                     const int pp = T + lanes_below(mask);
                                     tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
+                                    tw[tw_slot(pp)] = -(float)(xj * xj + yj * yj + zj * zj);
                                     if (MODE != 1) ttyp[pp] = (uint8_t)gtyp[u];
                                     if (MODE == 0) trad[pp] = grad[u];
                                 }

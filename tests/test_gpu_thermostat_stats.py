@@ -47,7 +47,9 @@ def test_per_atom_energy_ledger_and_plateau_in_a_force_free_gas():
     m = 39.9 * MSC
     model = api.Model.from_case(case)
     ph = model.query("photons", seed=12345)
-    assert len(ph) == N and 4.5 * KB * 298.0 < ph.mean() < 5.5 * KB * 298.0       # Gamma(5, kT): mean 5 kT (temperature.cpp:28-89)
+    # Gamma(5, kT) by bisection of its CDF (temperature.cpp:28-89): mean 5 kT in exact arithmetic; the reference's stopping rule (|residual| <
+    # 1e-3 on the un-normalised equation, at most 20 halvings, else the previous atom's value) biases the table low: 4.36 kT at 298 K
+    assert len(ph) == N and 4.0 * KB * 298.0 < ph.mean() < 5.5 * KB * 298.0
     e = api.Engine(model, seed=12345)
     prev = e.state()
     assert np.all(prev["fx"] == 0.0) and np.all(prev["U"] == 0.0)
