@@ -84,7 +84,7 @@ class _State(C.Structure):
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
 
-EXPORTS = ("aztot_init_md", "aztot_model_create", "aztot_model_set_bonded", "aztot_model_query", "aztot_model_species_name", "aztot_free_md", "aztot_default_options",
+EXPORTS = ("aztot_device_count", "aztot_init_md", "aztot_model_create", "aztot_model_set_bonded", "aztot_model_query", "aztot_model_species_name", "aztot_free_md", "aztot_default_options",
            "aztot_init_device", "aztot_free_device", "aztot_step", "aztot_forces", "aztot_get_stats", "aztot_species_crossings", "aztot_md_to_host",
            "aztot_set_state", "aztot_cell_table", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id", "aztot_comm_selftest", "aztot_comm_ranks",
            "aztot_init_device_slab", "aztot_last_error", "aztot_version")
@@ -401,6 +401,12 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+def device_count():
+    """HIP devices visible to this process (through libaztot, i.e. the system ROCm runtime: importing torch into a process that later
+    brings up RCCL would put torch's bundled, un-initialised HSA copy in front of it)."""
+    return int(lib().aztot_device_count())
 
 
 def rccl_unique_id():

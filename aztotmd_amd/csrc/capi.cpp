@@ -179,6 +179,13 @@ int aztot_model_query(const aztot_model* h, const char* key, double* out, int ca
     return status == AZTOT_OK ? rc : status;
 }
 
+int aztot_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n < 0 ? 0 : n;
+}
+
 void aztot_default_options(aztot_options* opt)
 {
     if (!opt) return;

@@ -63,6 +63,7 @@ private:
     void sort_and_forces(bool integrate_first, bool withBonded = true);
     void launch_step_kernels();
     void launch_pair();
+    int pair_variant() const;
     void exchange_halo();
     void collect_and_finalize(unsigned slotMask);
     void finish_steps();
@@ -100,6 +101,7 @@ private:
     char* dMsg_[4] = {nullptr, nullptr, nullptr, nullptr};   // sendLeft, sendRight, fromLeft, fromRight
     MsgLayout lay_{};
     int pairBlocks_ = 0, pairBlocksUsed_ = 0;
+    CellBins bins_{};               // per-cell bins of 16 atoms for pair kernel 3 (all-null when that kernel cannot run)
     BondedTables bonded_{};         // all-null when the model has no bonds / angles
     bool hasBonded_ = false;
     bool thermoTouched_ = false;    // the caller set U / radius on a run whose model does not use them: keep them attached to their atoms

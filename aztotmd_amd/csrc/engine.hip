@@ -12,6 +12,7 @@
 #include "ewald.hip.h"
 #include "kernels.hip.h"
 #include "pair_tile.hip.h"
+#include "pair_quad.hip.h"
 #include "slab.hip.h"
 
 namespace aztot {
@@ -200,13 +201,11 @@ void Engine::construct()
     {
         // who applies the second half-kick on plain NVE steps (nothing is added to the pair forces, nothing rescales velocities)
         const bool plainNve = !(P_.nEq > 0) && P_.tstat == AZTOT_TSTAT_NONE && !hasBonded_ && !hasEwald_ && !(opt_.reserved[0] & 128);
-        int variant = opt_.pair_variant;
-        if (variant == 0) variant = pair_tile_supported(P_) ? 2 : 1;
-        if (variant == 2 && !pair_tile_supported(P_)) variant = 1;
+        const int variant = pair_variant();
         // small systems / slabs are bound by launch latency: the tile kernel's epilogue does it (one kernel less: C2 0.083 -> 0.063 ms).
         // On 1 M atoms that 13-lane read-modify-write of the velocities makes L2 write lines back several times (rocprofv3: 221 MB
         // instead of 63 + 76 MB per step) for no gain, so large systems fold it into the next step's streaming k_integrate1_bin.
-        fuseEpilogue_ = plainNve && variant == 2 && capacity_ <= kFuseKickMaxAtoms && !(opt_.reserved[0] & 256);   // debug bit 256: large-system path
+        fuseEpilogue_ = plainNve && variant >= 2 && capacity_ <= kFuseKickMaxAtoms && !(opt_.reserved[0] & 256);   // debug bit 256: large-system path
         lazyKick_ = plainNve && !fuseEpilogue_;
     }
     if (nranks_ > 1 && !xch_)
@@ -333,6 +332,18 @@ void Engine::allocate()
             DevPot& d = pots[(size_t)a * ns + b];
             d.type = p.type; d.use_radii = p.use_radii; d.p0 = p.p0; d.p1 = p.p1; d.p2 = p.p2; d.p3 = p.p3; d.p4 = p.p4; d.r2cut = p.r2cut;
         }
+    {   // bins for pair kernel 3: only where it can run (stencil half-width 1, a specialised potential set, moderate density)
+        const bool specialised = P_.single_lj || P_.pad1 == 2;
+        const int perCell = pair_quad_bins_per_cell((double)capacity_ / std::max(1, P_.nCellLocal));
+        // opt-in (pair_variant 3): measured on the 1 M-atom box it is 8 % SLOWER than the one-wave tile kernel
+        if (opt_.pair_variant == 3 && specialised && pair_quad_supported(P_) && pair_quad_density_ok(perCell))
+        {
+            const size_t nSlots = (size_t)P_.nCellLocal * perCell * 16;
+            bins_.perCell = perCell;
+            bins_.x = (double*)alloc(sizeof(double) * nSlots); bins_.y = (double*)alloc(sizeof(double) * nSlots); bins_.z = (double*)alloc(sizeof(double) * nSlots);
+            bins_.type = (int32_t*)alloc(sizeof(int32_t) * nSlots);
+        }
+    }
     dPots_ = (DevPot*)alloc(sizeof(DevPot) * pots.size());
     HIP_CHECK(hipMemcpyAsync(dPots_, pots.data(), sizeof(DevPot) * pots.size(), hipMemcpyHostToDevice, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
@@ -532,12 +543,28 @@ void Engine::upload_initial()
 // ---------------------------------------------------------------------------------------------------
 // pair kernel dispatch
 // ---------------------------------------------------------------------------------------------------
+// which pair kernel runs: 1 per-atom gather (any geometry), 2 one wave per cell with its own LDS tile, 3 four waves share the tile of
+// four z-consecutive cells (cell edge >= cut-off, no generic potential mix).  0 = the best one that supports the system
+int Engine::pair_variant() const
+{
+    const bool quadOk = bins_.x != nullptr;          // allocate(): geometry, potential set and density allow k_pair_quad
+    int variant = opt_.pair_variant;
+    if (variant == 0) variant = quadOk ? 3 : (pair_tile_supported(P_) ? 2 : 1);
+    if (variant == 3 && !quadOk) variant = 2;
+    if (variant == 2 && !pair_tile_supported(P_)) variant = 1;
+    return variant;
+}
+
 void Engine::launch_pair()
 {
-    int variant = opt_.pair_variant;
-    if (variant == 0) variant = pair_tile_supported(P_) ? 2 : 1;
-    if (variant == 2 && !pair_tile_supported(P_)) variant = 1;
-    if (variant == 2)
+    const int variant = pair_variant();
+    if (variant == 3)
+    {
+        StepParams Q = P_;
+        Q.fuseKick = fuseNow_ ? 1 : 0;
+        timed("pair_quad", [&] { launch_pair_quad(Q, S_, dPots_, cur(), bins_, dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_); });
+    }
+    else if (variant == 2)
     {
         StepParams Q = P_;
         Q.fuseKick = fuseNow_ ? 1 : 0;
@@ -548,8 +575,8 @@ void Engine::launch_pair()
             hipLaunchKernelGGL(k_pair_atom, dim3(div_up(capacity_, kBlock)), dim3(kBlock), 0, stream_, P_, S_, dPots_, cur(), dCounts_, dCellStart_,
                                dCellOfSorted_, dPartials_, maxBlocks_);
         });
-    if (variant != 2) fuseNow_ = false;          // only the tile kernel has the fused epilogue (cannot happen: see the constructor)
-    pairBlocksUsed_ = (variant == 2) ? pair_tile_grid(P_) : div_up(capacity_, kBlock);
+    if (variant < 2) fuseNow_ = false;           // only the tile kernels have the fused epilogue (cannot happen: see the constructor)
+    pairBlocksUsed_ = (variant == 3) ? pair_quad_grid(P_) : (variant == 2) ? pair_tile_grid(P_) : div_up(capacity_, kBlock);
 }
 
 // one message to each x-neighbour: migrants + halo (packed by k_integrate1_bin; protocol in slab.hip.h)
@@ -601,7 +628,7 @@ void Engine::sort_and_forces(bool integrate_first, bool withBonded)
     });
     timed("rank_gather", [&] {
         hipLaunchKernelGGL(k_rank_gather, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellStart_, dTmpId_, dTmpSrc_, dTmpCell_, cur(), oth(),
-                           dCellOfSorted_, (P_.tstat == AZTOT_TSTAT_RADI || P_.use_radii || thermoTouched_) ? 2 : 0, P_, dCounts_, bonded_.idxOfId);
+                           dCellOfSorted_, (P_.tstat == AZTOT_TSTAT_RADI || P_.use_radii || thermoTouched_) ? 2 : 0, P_, dCounts_, bonded_.idxOfId, bins_);
     });
     cur_ ^= 1;
     launch_pair();
@@ -744,10 +771,13 @@ void Engine::step(int nsteps)
 
 void Engine::check_overflow()
 {
-    if (nranks_ <= 1 && !hasBonded_) return;
+    const bool quad = pair_variant() == 3;
+    if (nranks_ <= 1 && !hasBonded_ && !quad) return;
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
-    if (c.overflow) throw std::runtime_error("slab decomposition: a fixed-capacity halo/migration/atom buffer overflowed");
+    if (c.overflow && nranks_ <= 1)
+        throw std::runtime_error("pair kernel 3: the six cells of one z-column do not fit its LDS tile (> 170 atoms per cell locally); use pair_variant 2");
+    if (c.overflow) throw std::runtime_error("slab decomposition: a fixed-capacity halo/migration/atom buffer overflowed (or pair kernel 3's LDS tile)");
     if (c.bondedMissing)
         throw std::runtime_error("slab decomposition: a bond / angle partner was not resident on the rank that owns the atom "
                                  "(bonded terms must span less than the halo width)");

@@ -109,9 +109,8 @@ __device__ __forceinline__ void min_image(double& d, double L, double half)
 __device__ __forceinline__ double fast_rcp(double x)
 {
     double y = __builtin_amdgcn_rcp(x);
-    y = fma(fma(-x, y, 1.0), y, y);
-    y = fma(fma(-x, y, 1.0), y, y);
-    return y;
+    const double e = fma(-x, y, 1.0);            // one third-order step y (1 + e + e^2): error e^3 ~ 2^-72, three FMAs instead of the
+    return fma(y, fma(e, e, e), y);              // four of two Newton steps
 }
 
 // 1/sqrt(x): v_rsq_f64 refined by two Newton steps (y += y/2 (1 - x y^2)); 9 instructions for what gives r = x y, 1/r = y and
@@ -290,6 +289,7 @@ struct Counts
     int32_t nRecv;                  // atoms appended by k_unpack in the step in flight
     int32_t overflow;               // sticky: a fixed-capacity buffer was too small
     int32_t bondedMissing;          // sticky: a bond / angle partner was not resident on this rank (k_bonded)
+    int32_t reserved0;
 };
 
 __device__ __forceinline__ int wave_append(bool flag, int32_t* counter)
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
                                                         const int32_t* __restrict__ tmpId, const int32_t* __restrict__ tmpSrc,
                                                         const int32_t* __restrict__ tmpCell, AtomArrays src, AtomArrays dst,
                                                         int32_t* __restrict__ cellOfSorted, int carryForces /* bit 0: forces, bit 1: U + radius */, StepParams P, Counts* cntOut,
-                                                        int32_t* __restrict__ idxOfId)
+                                                        int32_t* __restrict__ idxOfId, CellBins B)
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p == 0)
@@ -572,7 +572,27 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
     for (int q = s; q < e; q++) rank += (tmpId[q] < myId) ? 1 : 0;
     const int d = s + rank;
     const int i = tmpSrc[p];
-    dst.x[d] = src.x[i]; dst.y[d] = src.y[i]; dst.z[d] = src.z[i];
+    const double x = src.x[i], y = src.y[i], z = src.z[i];
+    dst.x[d] = x; dst.y[d] = y; dst.z[d] = z;
+    if (B.x)
+    {   // the same atom in its cell's bins, relative to the centre of the cell it was binned into (count_cell: floor(x * cRevSize))
+        if (rank < 16 * B.perCell)
+        {
+            const int t = src.type[i];
+            const double cx = cell_coord(x, P.icsz[0], P.nc[0]) * P.csz[0] + 0.5 * P.csz[0];
+            const double cy = cell_coord(y, P.icsz[1], P.nc[1]) * P.csz[1] + 0.5 * P.csz[1];
+            const double cz = cell_coord(z, P.icsz[2], P.nc[2]) * P.csz[2] + 0.5 * P.csz[2];
+            const size_t g = ((size_t)c * B.perCell) * 16 + rank;
+            B.x[g] = x - cx; B.y[g] = y - cy; B.z[g] = z - cz; B.type[g] = t;
+            if (rank == e - s - 1)
+                for (int q = rank + 1; q & 15; q++)
+                {   // far-away, finite dummies behind the last atom of the cell, up to the end of its last bin
+                    const size_t gq = ((size_t)c * B.perCell) * 16 + q;
+                    B.x[gq] = -1e30; B.y[gq] = 0.0; B.z[gq] = 0.0; B.type[gq] = 0;
+                }
+        }
+        // atoms beyond the cell's bins (rank >= 16 perCell) are staged by the pair kernel from the per-atom arrays
+    }
     dst.vx[d] = src.vx[i]; dst.vy[d] = src.vy[i]; dst.vz[d] = src.vz[i];
     if (carryForces & 2) { dst.U[d] = src.U[i]; dst.rad[d] = src.rad[i]; }     // thermostat state: only when something reads it
     dst.type[d] = src.type[i]; dst.id[d] = myId;

@@ -78,7 +78,9 @@ constexpr int kPairTabStride = 8;   // {p0..p4, r2cut, kqq, potential type} per 
                                     // kernels sit at 10 192 B of LDS, and 10 240 B is the limit for 16 waves per CU (+64 B cost 7 %)
 constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-Jones / charge-product table in LDS
 
-template <int MODE, int VDW, int LG>
+// STRIDE: distance (in entries) between the x, y and z arrays of the tile; NW: 32-candidate mask words per round (3 for the one-wave
+// tile of <= 320 candidates, 4 for the shared tile of k_pair_quad whose windows hold ~400)
+template <int MODE, int VDW, int LG, int STRIDE = kTileLds, int NW = 3>
 __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots, const DevPot& lj,
                                             const double* tx, const double* ty, const double* tz, const float* tw, const uint8_t* ttyp, const double* trad,
                                             const double* pairTab, int T, int slice, double xi, double yi, double zi, int ti, double radi,
@@ -90,11 +92,11 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
     const double ljDropR2 = P.ljDropR2;                   // MODE 1: no pair beyond this r^2 can break the f^2 > 1e10 rule (Engine::construct)
     int nDropHalf = 0;
     if (P.pad0 & 2048) return;                             // measurement aid (bench.py --debug 2048): staging only, forces are wrong
-    for (int rb = 0; rb < iters; rb += 96)
+    for (int rb = 0; rb < iters; rb += 32 * NW)
     {
-        uint32_t m[3];
+        uint32_t m[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int w = 0; w < 3; w++)
+        for (int w = 0; w < NW; w++)
         {
             const int tb = rb + w * 32;
             const int nb = min(32, iters - tb);            // multiple of 4, may be <= 0
@@ -109,11 +111,11 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 // C/D[row 4 (l>>4) + reg][col l&15].  Rows are fed in the order perm(c) = (c >> 2) + 4 (c & 3), which makes register r of the
                 // lane (atom l&15, slice l>>4) the candidate 16 B + slice + 4 r: exactly the lane's own interleaved candidates; the
                 // -|rj|^2 of those four candidates arrive as the C operand through one 16-byte LDS read (tw is stored in that order).
-                const int lane = threadIdx.x;
+                const int lane = threadIdx.x & (kWave - 1);
                 const int c = lane & 15, k = lane >> 4;
                 const int permc = (c >> 2) + ((c & 3) << 2);
                 // lanes k = 3 feed the constant 1; they read (and ignore) the y array: banks 32-63, away from the z lanes of their half-wave
-                const double* pa = tx + (k == 3 ? 1 : k) * kTileLds + tb * NS + permc;
+                const double* pa = tx + (k == 3 ? 1 : k) * STRIDE + tb * NS + permc;
                 const float4_t* pc = (const float4_t*)(tw + tb * NS + 4 * k);
                 const int nblk = nb >> 2;                  // blocks of 16 candidates in this word (<= 8)
 #pragma unroll
@@ -161,15 +163,16 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
         // the register allocator from copying five 64-bit accumulators around in every iteration
         PairAcc rl = {0, 0, 0, 0, 0, 0};
         PairAcc& ra = (MODE == 1) ? rl : acc;              // measured: helps the LJ kernel (312 -> 309 us), hurts the Coulomb ones (629 -> 664)
-        uint32_t cur = m[0], nxt = m[1], lst = m[2];
-        if (P.pad0 & 1024) { acc.eV += (double)(cur ^ nxt ^ lst); continue; }     // measurement aid (--debug 1024): no pass 2, forces are wrong
+        uint32_t cur = m[0], nxt = m[1], lst = m[2], ult = m[3];
+        if (P.pad0 & 1024) { acc.eV += (double)(cur ^ nxt ^ lst ^ ult); continue; }     // measurement aid (--debug 1024): no pass 2, forces are wrong
         int kbase = rb * NS + slice;                       // tile index of bit 31 of `cur`
-        while (__any((cur | nxt | lst) != 0u))
+        while (__any((cur | nxt | lst | ult) != 0u))
         {
             const bool dry = cur == 0u;
             cur = dry ? nxt : cur;
             nxt = dry ? lst : nxt;
-            lst = dry ? 0u : lst;
+            if (NW > 3) { lst = dry ? ult : lst; ult = dry ? 0u : ult; }
+            else lst = dry ? 0u : lst;
             kbase += dry ? 32 * NS : 0;
             const bool live = cur != 0u;
             const int b = __clz(cur | 1u);
@@ -287,7 +290,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
         if (MODE == 1) { acc.fx += rl.fx; acc.fy += rl.fy; acc.fz += rl.fz; acc.eV += rl.eV; }
     }
     // dropped pairs were counted per wave (ballot popcount); book the wave total on lane 0 in "half pair" units
-    if (MODE != 0 && threadIdx.x == 0) acc.dropped += 0.5 * (double)nDropHalf;
+    if (MODE != 0 && (threadIdx.x & (kWave - 1)) == 0) acc.dropped += 0.5 * (double)nDropHalf;
 }
 
 template <int MODE, int VDW>   // 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;

@@ -175,6 +175,8 @@ int aztot_model_species_name(const aztot_model *m, int i, char *buf, int cap);
 void aztot_free_md(aztot_model *m);
 
 /* ---- device: replaces init_cudaMD / md_to_host / free_device_md (cuInit.h:4,6,7) --------------------- */
+/* number of HIP devices this process can use (0: none, never negative); the reference takes device 0 unasked (cuInit.cu:688) */
+int aztot_device_count(void);
 void aztot_default_options(aztot_options *opt);
 int aztot_init_device(const aztot_model *m, const aztot_options *opt, aztot_md **out);
 void aztot_free_device(aztot_md *md);

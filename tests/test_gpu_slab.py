@@ -14,9 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def transport_for(nranks):
     """RCCL (ncclSend/ncclRecv over xGMI, RcclExchanger::exchange) whenever every rank can have a GPU of its own; the host-staged
     gloo callback transport when the ranks have to share the one GPU of the development box (two RCCL ranks cannot share a device).
-    torch.cuda.device_count() does not initialise the GPU, and the workers are fresh torchrun children."""
-    import torch
-    return "rccl" if torch.cuda.device_count() >= nranks else "callback"
+    The device count comes from libaztot (the system ROCm runtime); torch is NOT imported into this process: its wheel bundles a second
+    copy of the HSA runtime, and RCCL brought up later in the same process would then find that un-initialised copy first
+    ("no ROCm-capable device is detected").  The workers are fresh torchrun children."""
+    from aztotmd_amd import api
+    return "rccl" if api.device_count() >= nranks else "callback"
 
 
 def run_ranks(nranks, name, nsteps, extra=None, port=29611, transport=None):
@@ -77,6 +79,13 @@ def test_slabs_with_per_atom_kernel():
     assert out["max_rel_err_vs_single"] < 1e-9
 
 
+@pytest.mark.parametrize("name,nranks,port", [("lj", 2, 29621), ("fennel", 3, 29622)])
+def test_slabs_with_one_wave_tile_kernel(name, nranks, port):
+    """pair_variant 2 (one wave per cell, own tile) on slab ranks; the default on these boxes is variant 3 (shared tile)"""
+    out = run_ranks(nranks, name, 15, extra={"pair_variant": 2}, port=port)
+    assert out["every_atom_owned_once"] and out["max_rel_err_vs_single"] < 1e-9, out["errs"]
+
+
 def test_rccl_library_selftest():
     """The slab transport's RCCL calls (dlopen'ed librccl, ncclCommInitRank, one ncclGroup of two sends + two receives in the
     N-GPU order, ncclAllReduce on the engine stream) on a one-rank communicator: the only way to run them on a one-GPU box."""
@@ -88,9 +97,9 @@ def test_rccl_library_selftest():
 def test_slabs_over_rccl(nranks, name, nsteps):
     """The production transport between real devices: one process per GPU, ncclSend/ncclRecv ring exchange + ncclAllReduce.  Needs
     as many GPUs as ranks (skipped on the one-GPU development box; runs as soon as the suite meets a multi-GPU node)."""
-    import torch
-    if torch.cuda.device_count() < nranks:
-        pytest.skip("needs %d GPUs, this machine has %d" % (nranks, torch.cuda.device_count()))
+    from aztotmd_amd import api
+    if api.device_count() < nranks:
+        pytest.skip("needs %d GPUs, this machine has %d" % (nranks, api.device_count()))
     out = run_ranks(nranks, name, nsteps, port=29700 + nranks, transport="rccl")
     assert out["rccl_ranks"] == nranks
     assert out["every_atom_owned_once"] and out["owned_total"] == out["n_atoms"]
