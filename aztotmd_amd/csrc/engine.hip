@@ -185,6 +185,9 @@ void Engine::construct()
         if (opt_.reserved[0] & 512) uniform = false;      // debug bit 512: take the generic kernel
         P_.pad1 = uniform ? 2 : 0;
         P_.vdwFamily = uniform ? family : 0;
+        // kernel specialisation 4: ONE species with the radius-dependent surk potential and no electrostatics (case study 2)
+        if (m.nSpec() == 1 && m.pairpots[0].type == AZTOT_VDW_SURK && m.pairpots[0].use_radii && m.elec_type == AZTOT_ELEC_NONE && !(opt_.reserved[0] & 512))
+            P_.pad1 = 4;
     }
     std::memset(&S_, 0, sizeof(S_));
     for (int i = 0; i < m.nSpec(); i++)
@@ -729,7 +732,9 @@ void Engine::step(int nsteps)
 {
     if (nsteps <= 0) return;
     int done = 0;
-    const bool can_graph = opt_.use_graph && nranks_ == 1 && !profile_;
+    // slab ranks: only with the loopback transport and only on request (debug bit 4096) - an experiment, see DESIGN.md section 6
+    const bool slabGraph = nranks_ > 1 && ownedXch_ && (opt_.reserved[0] & 4096) && !(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE);
+    const bool can_graph = opt_.use_graph && (nranks_ == 1 || slabGraph) && !profile_;
     if (can_graph && nsteps >= 2)
     {
         // a graph holds TWO consecutive steps (the sort ping-pongs between the two per-atom buffers), and there is

@@ -201,6 +201,25 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 }
                 ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
             }
+            else if (MODE == 4)
+            {   // one species, radius-dependent 'surk' potential (surk_pot cuVdW.cu:236-257; cuPairs.cu:145-146), no electrostatics: case
+                // study 2.  U = a b r^-6 (C1 a^2 b^2 / r - C2 / (ka a + kb b)) with a, b the radii the radiative thermostat writes
+                // (cuTemp.cu:757-759); same operation order as the generic kernel's vdw_force, branch-free like the Lennard-Jones body
+                const bool pairOk = live & (r2 > 0.0) & (r2 <= lj.r2cut);
+                const double r2s = pairOk ? r2 : 1e300;             // r^-6 underflows to 0: no energy, no force
+                const double ir = fast_rsqrt(r2s), r2i = ir * ir;
+                const double radj = trad[k];
+                const double c2ir_sum = lj.p1 * fast_rcp(lj.p2 * radi + lj.p3 * radj);
+                const double r_prod = radi * radj;
+                const double C1ab2 = r_prod * r_prod * lj.p0;
+                const double ir6 = r2i * r2i * r2i;
+                ra.eV = fma(0.5, r_prod * ir6 * (C1ab2 * ir - c2ir_sum), ra.eV);
+                const double f = r_prod * ir6 * r2i * (7.0 * C1ab2 * ir - 6.0 * c2ir_sum);
+                const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
+                nDropHalf += __popcll(__ballot(tooBig));
+                const double fm = tooBig ? 0.0 : f;
+                ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
+            }
             else if (MODE >= 2)
             {   // one potential family for every species pair (VDW: 1 lnjs, 2 buck, 3 p746, 4 bmhs - fer_* of vdw.cpp:16-157), electrostatics
                 // none, direct, Fennell/DSF (fennel elec.cpp:430-444) or the real-space Ewald term; parameters per species pair come from a
@@ -294,19 +313,20 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
 }
 
 template <int MODE, int VDW>   // 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;
-                      // 3: as 2 with the real-space term of the Ewald sum
-__global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
+                      // 3: as 2 with the real-space term of the Ewald sum ; 4: one species, surk with thermostat radii (case study 2)
+__global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks)
 {
+    constexpr bool kOneSpecies = (MODE == 1 || MODE == 4);           // no species table, no type ids
     __shared__ double txyz[3 * kTileLds];                            // candidate coordinates RELATIVE to the centre of the centre cell
     __shared__ float tw[kTileLds];                                   // -(x^2 + y^2 + z^2) of the same, f32: 4th operand row of the filter
     double* const tx = txyz;
     double* const ty = txyz + kTileLds;
     double* const tz = txyz + 2 * kTileLds;
-    __shared__ uint8_t ttyp[MODE != 1 ? kTileLds : 1];               // species ids (< 16)
-    __shared__ double trad[MODE == 0 ? kTileLds : 1];
-    __shared__ double pairTab[MODE >= 2 ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
+    __shared__ uint8_t ttyp[!kOneSpecies ? kTileLds : 1];               // species ids (< 16)
+    __shared__ double trad[(MODE == 0 || MODE == 4) ? kTileLds : 1];
+    __shared__ double pairTab[(MODE == 2 || MODE == 3) ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
     __shared__ int32_t entJ[kWave], entN[kWave], entC[kWave];       // staging table: first atom, count (<= 64), image-shift code
 
     const int lane = threadIdx.x;
@@ -332,7 +352,7 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
         const double ext2 = (h0 + rcut) * (h0 + rcut) + (h1 + rcut) * (h1 + rcut) + (h2 + rcut) * (h2 + rcut);
         const double filtThr = P.r2Max + 1.9073486328125e-06 * (4.0 * ext2 + P.r2Max);      // 2^-19
         const DevPot lj = pots[0];
-        if (MODE >= 2)
+        if (MODE == 2 || MODE == 3)
         {
             const int np = P.nSpec * P.nSpec;
             if (lane < np)
@@ -362,8 +382,8 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
             if (validI)
             {
                 xi = A.x[myi] - cc0; yi = A.y[myi] - cc1; zi = A.z[myi] - cc2;
-                if (MODE != 1) ti = A.type[myi];
-                if (MODE == 0 && P.use_radii) radi = A.rad[myi];
+                if (!kOneSpecies) ti = A.type[myi];
+                if ((MODE == 0 && P.use_radii) || MODE == 4) radi = A.rad[myi];
             }
             // matrix-filter operand of this lane (used when the cell has <= 16 atoms): component `slice` of (2 xi, 2 yi, 2 zi, thr - |ri|^2).
             // Idle atom slots sit at 1e30: their column of the filter is -inf ("outside") whatever the candidate
@@ -384,8 +404,8 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                 if (lane < kTilePad)
                 {
                     tx[T + lane] = -1e30; ty[T + lane] = 0.0; tz[T + lane] = 0.0; tw[tw_slot(T + lane)] = -3e38f;
-                    if (MODE != 1) ttyp[T + lane] = 0;          // a valid species: the parameter table is indexed with it
-                    if (MODE == 0) trad[T + lane] = 0.0;
+                    if (!kOneSpecies) ttyp[T + lane] = 0;          // a valid species: the parameter table is indexed with it
+                    if (MODE == 0 || MODE == 4) trad[T + lane] = 1.0;
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (lg == 4) tile_passes<MODE, VDW, 4>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
@@ -466,8 +486,8 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                             if (lane < gjn[u])
                             {
                                 gx[u] = ld_f64(A.x, j); gy[u] = ld_f64(A.y, j); gz[u] = ld_f64(A.z, j);
-                                if (MODE != 1) gtyp[u] = ld_i32(A.type, j);
-                                if (MODE == 0 && P.use_radii) grad[u] = ld_f64(A.rad, j);
+                                if (!kOneSpecies) gtyp[u] = ld_i32(A.type, j);
+                                if ((MODE == 0 && P.use_radii) || MODE == 4) grad[u] = ld_f64(A.rad, j);
                             }
                         }
 #pragma unroll
@@ -495,8 +515,8 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
                                     const int pp = T + lanes_below(mask);
                                     tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
                                     tw[tw_slot(pp)] = -(float)(xj * xj + yj * yj + zj * zj);
-                                    if (MODE != 1) ttyp[pp] = (uint8_t)gtyp[u];
-                                    if (MODE == 0) trad[pp] = grad[u];
+                                    if (!kOneSpecies) ttyp[pp] = (uint8_t)gtyp[u];
+                                    if (MODE == 0 || MODE == 4) trad[pp] = grad[u];
                                 }
                                 T += __popcll(mask);
                             }
@@ -518,7 +538,7 @@ __global__ __launch_bounds__(kWave, MODE >= 2 ? 3 : 1) void k_pair_tile(StepPara
             if (validI && slice == 0)
             {
                 double q = 0.0;
-                if (MODE != 1) q = S.charge[ti];
+                if (!kOneSpecies) q = S.charge[ti];
                 const double fxi = -q * P.E[0] + acc.fx;   // clear_force integrators.cpp:17-39
                 const double fyi = -q * P.E[1] + acc.fy;
                 const double fzi = -q * P.E[2] + acc.fz;
@@ -566,6 +586,7 @@ inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevP
                              double* partials, int maxBlocks, hipStream_t stream)
 {
     if (P.single_lj) { launch_pair_tile_as<1, 1>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return; }
+    if (P.pad1 == 4) { launch_pair_tile_as<4, 7>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return; }     // one species, surk + radii
     if (P.pad1 == 2)
     {
         const bool ew = P.elec_type == 2;

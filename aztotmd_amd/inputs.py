@@ -268,6 +268,12 @@ def config(name):
         c = lj_case((20, 20, 25), seed=20240504, charges=(0.2, -0.2), elec="fenn", r_real=8.5, alpha=0.35)
         c.update(elec_type=2, ewald_k=(12, 12, 14))
         return c
+    if name in ("S4", "S40"):   # periodic analogues of 'case study 2' (BASELINE config 5): surk rc 6.0 on 2.7 A cells, radii, radiative thermostat at 500 K;
+                                # 4 000 atoms at the case study's density (0.46 / A^3: ~410 neighbours inside rc) and a 40 000-atom box of the same
+        c = lj_case((10, 10, 10) if name == "S4" else (20, 20, 25), a=2.06, jitter=0.05, seed=20240507, rc=6.0, cell_list=2.7, T=500.0, tstat="radi",
+                    radii=[(2.73, 4.731, 0.2)])
+        c["vdw"] = [(0, 0, VDW_TYPES["surk"], 6.0, [75.0, 8.0, 1.0, 1.0])]
+        return c
     if name == "M4":      # 1 029 000 atoms: 343 000 bent triatomics (bonds + angles), LJ + Fennell  ("next" row f2)
         return molecular_case((70, 70, 70), seed=20240503, charges=(-0.2, 0.1), elec="fenn", quantize=False)
     raise KeyError(name)

@@ -225,7 +225,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": {"C4": "1 000 188 Ar, LJ rc 8.5 A, FCC 63^3 a=5.735 jitter 0.15, dt 1 fs, NVE (BASELINE config '1 000 000 Ar LJ', SURVEY C4)",
                                     "C3": "1 000 188 atoms, LJ rc 8.5 A + Fennell/DSF Coulomb q=+-0.2 (SURVEY C3)",
-                                    "C2": "40 000 Ar, LJ rc 8.5 A (SURVEY C2)"}.get(a.workload, a.workload),
+                                    "C2": "40 000 Ar, LJ rc 8.5 A (SURVEY C2)",
+                                    "S4": "4 000 atoms, surk rc 6.0 + radii on 2.7 A cells, radiative thermostat 500 K (periodic analogue of case study 2)",
+                                    "S40": "40 000 atoms, surk rc 6.0 + radii on 2.7 A cells, radiative thermostat 500 K"}.get(a.workload, a.workload),
                        "n_atoms": n_atoms, "n_cells": st["n_cells"], "decomposition": "single GPU" if world == 1 else "%d slabs along x" % world, "transport": transport, "rccl_ranks": rccl_ranks, "ranks_share_gpus": oversubscribed,
                        "pair_variant": a.pair_variant,
                        "kernel_timing": "second pass of the same %d steps with HIP events on the engine stream" % a.steps if profile else "off"},

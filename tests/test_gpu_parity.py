@@ -379,6 +379,37 @@ def test_surk_radius_potential_with_thermostat():
         assert abs(e.stats()["engVdW"] - o.stats()["engVdW"]) <= 1e-10 * abs(o.stats()["engVdW"])
 
 
+@pytest.mark.parametrize("cell", [2.7, 6.0])
+def test_surk_tile_mode_equals_generic_kernel_and_oracle(cell):
+    """the specialised one-species surk + radii tile mode (case study 2 / BASELINE config 5) against the generic kernel (debug bit 512),
+    the per-atom kernel and the oracle: forces 1e-11, 20 thermostatted steps 1e-9; on the case study's 2.7 A cells (7^3 stencil) and on
+    cut-off sized cells"""
+    pos, box = inputs.fcc_positions((7, 7, 8), 2.9, 0.12, 9)
+    N = len(pos)
+    case = {"box": box.tolist(), "dt": 0.001, "species": [(39.9, 0.0)], "names": ["Ar"], "types": np.zeros(N, dtype=np.int32),
+            "vdw": [(0, 0, 7, 6.0, [75.0, 8.0, 1.0, 1.0])], "radii": [(2.73, 4.731, 0.2)], "x": pos[:, 0].copy(), "y": pos[:, 1].copy(),
+            "z": pos[:, 2].copy(), "vx": np.zeros(N), "vy": np.zeros(N), "vz": np.zeros(N), "T": 500.0, "tstat_type": 2,
+            "cell_list": cell, "use_clist": 1, "elec_type": 0}
+    o = oracle.Oracle(case)
+    o.forces(0)
+    so, sto = o.state(), o.stats()
+    engines = [engine(case), engine(case, debug=512), engine(case, pair_variant=1)]
+    for e in engines:
+        s, st = e.state(), e.stats()
+        for k in FKEYS:
+            assert rel_err(s[k], so[k]) < 1e-11, (k, rel_err(s[k], so[k]))
+        assert abs(st["engVdW"] - sto["engVdW"]) <= 1e-12 * abs(sto["engVdW"])
+    o.step(20)
+    for e in engines[:2]:
+        e.step(20)
+        s, so = e.state(), o.state()
+        for a, b in (("x", "x"), ("vx", "vx"), ("fx", "fx"), ("U", "U"), ("radius", "rad")):
+            assert rel_err(s[a], so[b]) < 1e-9, (a, rel_err(s[a], so[b]))
+    # the two tile modes agree to round-off (same operation order per pair)
+    for k in ("fx", "fy", "fz"):
+        assert rel_err(engines[0].state()[k], engines[1].state()[k]) < 1e-13
+
+
 def test_input_files_round_trip(tmp_path):
     """atoms.xyz / field.txt / control.txt / cuda.txt written in the reference grammar give the same run."""
     case = inputs.config("F3")
