@@ -158,15 +158,14 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
         // pass 2: every lane pops its own hits.  `cur` is the word being drained, `nxt`/`lst` the ones still waiting; when
         // `cur` runs dry the next word slides in (selects, no branches), so a lane keeps busy as long as ANY of its three
         // words has hits left - the wave loops max-over-lanes(hits per lane) times, not sum-over-words(max per word).
-        // The body is branch-free: lanes without a hit run on a dummy candidate and are masked out.
-        // round-local accumulators (folded into `acc` after the loop): the loop-carried values then start from constants, which keeps
-        // the register allocator from copying five 64-bit accumulators around in every iteration
-        PairAcc rl = {0, 0, 0, 0, 0, 0};
-        PairAcc& ra = (MODE == 1) ? rl : acc;              // measured: helps the LJ kernel (312 -> 309 us), hurts the Coulomb ones (629 -> 664)
+        // Lanes whose words are empty sit the iteration out (EXEC mask: two scalar instructions, where selecting a dummy candidate and
+        // carrying a `live` flag through the cut-off test cost three vector ones); the body itself is branch-free.  The loop is a
+        // do-while on purpose: with the exit test at the top the compiler copies the five 64-bit accumulators in every iteration.
+        PairAcc& ra = acc;
         uint32_t cur = m[0], nxt = m[1], lst = m[2], ult = m[3];
-        if (P.pad0 & 1024) { acc.eV += (double)(cur ^ nxt ^ lst ^ ult); continue; }     // measurement aid (--debug 1024): no pass 2, forces are wrong
         int kbase = rb * NS + slice;                       // tile index of bit 31 of `cur`
-        while (__any((cur | nxt | lst | ult) != 0u))
+        if (__any((cur | nxt | lst | ult) != 0u))
+        do
         {
             const bool dry = cur == 0u;
             cur = dry ? nxt : cur;
@@ -174,10 +173,14 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
             if (NW > 3) { lst = dry ? ult : lst; ult = dry ? 0u : ult; }
             else lst = dry ? 0u : lst;
             kbase += dry ? 32 * NS : 0;
+            // (the Coulomb bodies are the exception: measured on C3 they lose 3 % to the EXEC-masked form, so they keep the dummy candidate)
+            constexpr bool kMaskBody = (MODE == 1 || MODE == 4);
             const bool live = cur != 0u;
+            if (kMaskBody ? live : true)
+            {
             const int b = __clz(cur | 1u);
             cur &= ~(0x80000000u >> b);                    // for a dry word this clears bit 0 of zero: harmless
-            const int k = live ? kbase + b * NS : T;       // dead lanes: the first dummy
+            const int k = (kMaskBody || live) ? kbase + b * NS : T;       // dead lanes of the unmasked form: the first dummy
             const double dx = xi - tx[k], dy = yi - ty[k], dz = zi - tz[k];
             const double r2 = dx * dx + dy * dy + dz * dz;
             if (MODE == 1)
@@ -196,7 +199,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 if (__builtin_expect(__any(r2s < ljDropR2), 0))
                 {
                     const bool tooBig = fm * fm > 1e10;
-                    nDropHalf += __popcll(__ballot(tooBig));
+                    nDropHalf += tooBig ? 1 : 0;
                     fm = tooBig ? 0.0 : fm;
                 }
                 ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
@@ -216,7 +219,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 ra.eV = fma(0.5, r_prod * ir6 * (C1ab2 * ir - c2ir_sum), ra.eV);
                 const double f = r_prod * ir6 * r2i * (7.0 * C1ab2 * ir - 6.0 * c2ir_sum);
                 const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
-                nDropHalf += __popcll(__ballot(tooBig));
+                nDropHalf += tooBig ? 1 : 0;
                 const double fm = tooBig ? 0.0 : f;
                 ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
             }
@@ -299,17 +302,17 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                     f = fma(kqq * ir, r2i, f);
                 }
                 const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
-                nDropHalf += __popcll(__ballot(tooBig));
+                nDropHalf += tooBig ? 1 : 0;
                 const double fm = tooBig ? 0.0 : f;
                 ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
             }
             else if (live && r2 > 0.0 && r2 <= P.r2Max)
                 pair_visit(P, S, pots, dx, dy, dz, r2, ti, ttyp[k], radi, trad[k], ra);
-        }
-        if (MODE == 1) { acc.fx += rl.fx; acc.fy += rl.fy; acc.fz += rl.fz; acc.eV += rl.eV; }
+            }
+        } while (__any((cur | nxt | lst | ult) != 0u));
     }
-    // dropped pairs were counted per wave (ballot popcount); book the wave total on lane 0 in "half pair" units
-    if (MODE != 0 && (threadIdx.x & (kWave - 1)) == 0) acc.dropped += 0.5 * (double)nDropHalf;
+
+    if (MODE != 0) acc.dropped += 0.5 * (double)nDropHalf;     // dropped pairs, counted per lane in "half pair" units (every pair is visited from both ends)
 }
 
 template <int MODE, int VDW>   // 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;
