@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kWave* kQuadR, 4) void k_pair_quad(StepParams P, Sp
 {
     static_assert(MODE >= 1, "the generic potential mix stays with k_pair_tile");
     __shared__ double txyz[3 * kQuadTile];                           // candidate coordinates relative to the centre of the group of cells
-    __shared__ float tw[kQuadTile];                                  // -(x^2 + y^2 + z^2), transposed inside blocks of 16 (tw_slot)
+    __shared__ float tw[kQuadTile];                                  // -(x^2 + y^2 + z^2): 4th operand row of the distance filter
     __shared__ uint8_t ttyp[MODE != 1 ? kQuadTile : 1];
     __shared__ double pairTab[MODE >= 2 ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
     __shared__ int32_t binCell[kQuadBins];                           // per tile bin: cell-table lane it belongs to | bin number inside the cell << 8
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kWave* kQuadR, 4) void k_pair_quad(StepParams P, Sp
                 if (lane < 16)
                 {   // one bin of far-away, finite dummies behind the last bin: what dead lanes of pass 2 chew on
                     const int idx = nBinsTot * 16 + lane;
-                    tx[idx] = -1e30; ty[idx] = 0.0; tz[idx] = 0.0; tw[tw_slot(idx)] = -3e38f;
+                    tx[idx] = -1e30; ty[idx] = 0.0; tz[idx] = 0.0; tw[idx] = -3e38f;
                     if (MODE != 1) ttyp[idx] = 0;
                 }
             }
@@ -229,7 +229,6 @@ __global__ __launch_bounds__(kWave* kQuadR, 4) void k_pair_quad(StepParams P, Sp
 
             // ---- staging: 64 lanes copy 4 bins per round; rounds are dealt to the waves in turn
             const int slot = lane & 15;
-            const int slotW = ((slot & 3) << 2) | (slot >> 2);             // tw_slot inside the bin
             for (int q0 = wave * 4; q0 < nBinsTot; q0 += 4 * kQuadR)
             {   // (wave-uniform loop: the cross-lane reads below need every lane of the cell table switched on)
                 const int q = q0 + (lane >> 4);
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(kWave* kQuadR, 4) void k_pair_quad(StepParams P, Sp
                     xj += ox; yj += oy; zj += oz;
                     const int pp = q * 16 + slot;
                     tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
-                    tw[q * 16 + slotW] = -(float)(xj * xj + yj * yj + zj * zj);
+                    tw[pp] = -(float)(xj * xj + yj * yj + zj * zj);
                     if (MODE != 1) ttyp[pp] = (uint8_t)tj;
                 }
             }

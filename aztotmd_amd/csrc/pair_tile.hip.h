@@ -28,9 +28,6 @@ static_assert(kTileLds % 32 == 16, "coordinate arrays must be staggered by half 
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
-// where -|r|^2 of tile entry p lives: inside every block of 16 the order is transposed (entry s + 4 r at 4 s + r), so that the four
-// candidates a lane owns in a block (slice s: s, s + 4, s + 8, s + 12) are one aligned 16-byte read
-__device__ __forceinline__ int tw_slot(int p) { return (p & ~15) | ((p & 3) << 2) | ((p >> 2) & 3); }
 
 // the tile kernel needs every neighbour cell to be reached through exactly one periodic image
 inline bool pair_tile_supported(const StepParams& P)
@@ -110,13 +107,13 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                 // the same fp64 units as v_fma_f64 (measured: additive).  Operand maps (gfx950): A[row l&15][k l>>4], B[k l>>4][col l&15],
                 // C/D[row 4 (l>>4) + reg][col l&15].  Rows are fed in the order perm(c) = (c >> 2) + 4 (c & 3), which makes register r of the
                 // lane (atom l&15, slice l>>4) the candidate 16 B + slice + 4 r: exactly the lane's own interleaved candidates; the
-                // -|rj|^2 of those four candidates arrive as the C operand through one 16-byte LDS read (tw is stored in that order).
+                // -|rj|^2 of those four candidates arrive as the C operand.
                 const int lane = threadIdx.x & (kWave - 1);
                 const int c = lane & 15, k = lane >> 4;
                 const int permc = (c >> 2) + ((c & 3) << 2);
                 // lanes k = 3 feed the constant 1; they read (and ignore) the y array: banks 32-63, away from the z lanes of their half-wave
                 const double* pa = tx + (k == 3 ? 1 : k) * STRIDE + tb * NS + permc;
-                const float4_t* pc = (const float4_t*)(tw + tb * NS + 4 * k);
+                const float* pc = tw + tb * NS + k;        // -|rj|^2 of the lane's candidates k, k + 4, k + 8, k + 12 of every block
                 const int nblk = nb >> 2;                  // blocks of 16 candidates in this word (<= 8)
 #pragma unroll
                 for (int q = 0; q < 8; q++)
@@ -125,7 +122,8 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
                     {
                         const float av = (float)pa[q * 16];
                         const float a = (k == 3) ? 1.0f : av;
-                        const float4_t d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, filtB, pc[q * 4], 0, 0, 0);
+                        const float4_t cw = {pc[q * 16], pc[q * 16 + 4], pc[q * 16 + 8], pc[q * 16 + 12]};      // two ds_read2_b32
+                        const float4_t d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, filtB, cw, 0, 0, 0);
                         miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[0]), 31);
                         miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[1]), 31);
                         miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[2]), 31);
@@ -406,7 +404,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                 // harmless candidate to chew on (uninitialised LDS could hold NaN patterns: 0 * NaN would poison a force)
                 if (lane < kTilePad)
                 {
-                    tx[T + lane] = -1e30; ty[T + lane] = 0.0; tz[T + lane] = 0.0; tw[tw_slot(T + lane)] = -3e38f;
+                    tx[T + lane] = -1e30; ty[T + lane] = 0.0; tz[T + lane] = 0.0; tw[T + lane] = -3e38f;
                     if (!kOneSpecies) ttyp[T + lane] = 0;          // a valid species: the parameter table is indexed with it
                     if (MODE == 0 || MODE == 4) trad[T + lane] = 1.0;
                 }
@@ -517,7 +515,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                                 {
                                     const int pp = T + lanes_below(mask);
                                     tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
-                                    tw[tw_slot(pp)] = -(float)(xj * xj + yj * yj + zj * zj);
+                                    tw[pp] = -(float)(xj * xj + yj * yj + zj * zj);
                                     if (!kOneSpecies) ttyp[pp] = (uint8_t)gtyp[u];
                                     if (MODE == 0 || MODE == 4) trad[pp] = grad[u];
                                 }
