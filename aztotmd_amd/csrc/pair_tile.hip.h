@@ -185,22 +185,25 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
             {   // fer_lj vdw.cpp:16-26 ; pair_inter integrators.cpp:139-185.  The atom itself (r2 == 0 exactly: its own
                 // cell is part of the tile, unshifted), candidates the conservative filter let through and dead lanes
                 // are pushed out to a huge r2, where sr6 underflows to exactly 0 and with it energy and force.
-                const bool pairOk = live & (r2 > 0.0) & (r2 <= lj.r2cut);
-                const double r2s = pairOk ? r2 : 1e300;
-                const double r2i = fast_rcp(r2s);
-                const double sr2 = lj.p1 * r2i;
-                const double sr6 = sr2 * sr2 * sr2;
-                ra.eV = fma(0.5 * lj.p0, sr6 * (sr6 - 1.0), ra.eV);
-                double fm = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
-                // integrators.cpp:170-174: a pair with f^2 > 1e10 is dropped.  |f| grows monotonically as r shrinks below the minimum, so the
-                // exact test is only reached (wave-uniform branch, practically never) when some lane is inside a generous radius
-                if (__builtin_expect(__any(r2s < ljDropR2), 0))
+                // The exact cut-off test and the self pair also go through the EXEC mask: the filter is conservative by 1e-5, so next to the
+                // atom's own copy (one hit in ~57) practically every lane passes and nothing diverges
+                if ((r2 > 0.0) & (r2 <= lj.r2cut))
                 {
-                    const bool tooBig = fm * fm > 1e10;
-                    nDropHalf += tooBig ? 1 : 0;
-                    fm = tooBig ? 0.0 : fm;
+                    const double r2i = fast_rcp(r2);
+                    const double sr2 = lj.p1 * r2i;
+                    const double sr6 = sr2 * sr2 * sr2;
+                    ra.eV = fma(0.5 * lj.p0, sr6 * (sr6 - 1.0), ra.eV);
+                    double fm = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
+                    // integrators.cpp:170-174: a pair with f^2 > 1e10 is dropped.  |f| grows monotonically as r shrinks below the minimum, so
+                    // the exact test is only reached (wave-uniform branch, practically never) when some lane is inside a generous radius
+                    if (__builtin_expect(__any(r2 < ljDropR2), 0))
+                    {
+                        const bool tooBig = fm * fm > 1e10;
+                        nDropHalf += tooBig ? 1 : 0;
+                        fm = tooBig ? 0.0 : fm;
+                    }
+                    ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
                 }
-                ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
             }
             else if (MODE == 4)
             {   // one species, radius-dependent 'surk' potential (surk_pot cuVdW.cu:236-257; cuPairs.cu:145-146), no electrostatics: case

@@ -245,6 +245,21 @@ def ewald_case(**kw):
     return c
 
 
+def test_ewald_with_more_than_64k_of_lds():
+    """kx + ky + kz = 57 harmonics: the force kernel needs 69 KiB of dynamic LDS, above the 64 KiB a launch gets without asking
+    (hipFuncSetAttribute in upload_ewald; before, the launch was rejected silently and the reciprocal forces were missing)."""
+    case = ewald_case(ewald_k=(19, 19, 19))
+    o = oracle.Oracle(case)
+    o.forces(0)
+    so, sto = o.state(), o.stats()
+    e = engine(case)
+    s, st = e.state(), e.stats()
+    for k in FKEYS:
+        assert rel_err(s[k], so[k]) < 1e-11, (k, rel_err(s[k], so[k]))
+    assert abs(st["engCoulRec"] - sto["engElec2"]) <= 1e-12 * abs(sto["engElec2"])
+    assert sto["engElec2"] != 0.0
+
+
 @pytest.mark.parametrize("kw", [{}, dict(ewald_k=(4, 7, 9)), dict(cell_list=3.4)])
 def test_ewald_forces_match_oracle(kw):
     """reciprocal + real-space + constant parts of the Ewald sum against the oracle (forces 1e-11, energies 1e-12)."""

@@ -250,6 +250,31 @@ def test_reference_case_studies(sub):
         assert o["n_atoms"] == 4000 and o["vdw"][0][0]["type"] == 7 and o["vdw"][0][0]["use_radii"] == 1 and o["rmax"] == 6.0
 
 
+@pytest.mark.parametrize("k", [1, 2])
+def test_case_study_fixtures(k, tmp_path):
+    """the reference's shipped example inputs, kept as data in tests/golden/case_study_k.npz: the four files written back from the fixture
+    parse identically in the product's C++ parser and in the Python restatement - on any machine, also where the reference tree is absent -
+    and (where it is present) are byte-identical to the originals, DOS line ends included."""
+    import filecmp
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import materialise_case_study
+    d = materialise_case_study(k, str(tmp_path / ("cs%d" % k)))
+    m, o = compare(d)
+    if k == 1:
+        assert o["n_atoms"] == 40000 and o["elec_type"] == 0 and o["rmax"] == 4.0 and o["cell_list"] == 85.0 and o["tstat_type"] == 2
+        assert o["nstep"] == 100000 and o["stat"] == 200
+    else:
+        assert o["n_atoms"] == 4000 and o["vdw"][0][0]["type"] == 7 and o["vdw"][0][0]["use_radii"] == 1 and o["rmax"] == 6.0
+        assert o["cell_list"] == 2.7 and o["nequil"] == 10000 and o["eqfreq"] == 2500 and o["species"][0]["radA"] == 2.73
+    ref = os.path.join(REF, "case study %d" % k)
+    if os.path.isdir(ref):
+        for f in ("atoms.xyz", "field.txt", "control.txt", "cuda.txt"):
+            assert filecmp.cmp(os.path.join(d, f), os.path.join(ref, f), shallow=False), f
+    d2 = materialise_case_study(k, str(tmp_path / "cut"), nstep=20)          # the test harness may shorten the run, nothing else
+    assert parse.parse_dir(d2, with_atoms=False)["nstep"] == 20
+
+
 def test_thermostat_tables_match_oracle():
     from oracle import oracle
     case = inputs.lj_case((3, 3, 3), a=5.26, seed=11, rc=6.5, T=298.0, tstat="radi", radii=[(2.73, 4.731, 0.2)])
