@@ -26,7 +26,7 @@ constexpr double pressure_factor = 1.58e6;                 // main.cpp:147 / mai
 
 constexpr int kMaxSpecies = 15;                            // defines.h:14 MX_SPEC
 constexpr int kNumUnitVectors = 3072;                      // cuTemp.h:4 nUvect
-constexpr int kEwaldKMax = 16;                             // k-vectors per axis the Ewald kernels size their LDS tables for (reference: NKVEC_MX)
+constexpr int kEwaldKMax = 48;                             // k-vectors per axis: the Ewald kernels keep kx + ky + kz harmonics x 1 KiB in LDS (<= 160 KiB, checked in upload_ewald; reference: NKVEC_MX 100)
 
 struct Species                                             // Spec, dataStruct.h:244-291
 {
