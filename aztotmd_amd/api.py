@@ -11,7 +11,7 @@ _LIB = None
 
 STAT_FIELDS = ("step", "time", "engTot", "engKin", "engVdW", "engCoul", "engElecField", "engTemp", "engPot", "temperature",
                "posMom", "negMom", "posCross", "negCross", "pressure", "pairs_dropped", "n_cells", "nose_chit", "nose_conint",
-               "engBond", "engAngle", "engCoulRec", "engCoulConst")
+               "engBond", "engAngle", "engCoulRec", "engCoulConst", "sort_interval", "sort_violations")
 
 
 class AztotError(RuntimeError):
@@ -74,7 +74,7 @@ class _Stats(C.Structure):
                 ("temperature", C.c_double), ("posMom", C.c_double * 3), ("negMom", C.c_double * 3), ("posCross", C.c_int64 * 3),
                 ("negCross", C.c_int64 * 3), ("pressure", C.c_double), ("pairs_dropped", C.c_int64), ("n_cells", C.c_int64),
                 ("nose_chit", C.c_double), ("nose_conint", C.c_double), ("engBond", C.c_double), ("engAngle", C.c_double),
-                ("engCoulRec", C.c_double), ("engCoulConst", C.c_double)]
+                ("engCoulRec", C.c_double), ("engCoulConst", C.c_double), ("sort_interval", C.c_int64), ("sort_violations", C.c_int64)]
 
 
 class _State(C.Structure):
@@ -262,7 +262,7 @@ class Engine:
     """Device state + step driver (reference: cudaMD + the loop body of main.cu:281-410)."""
 
     def __init__(self, model, device=0, initial_forces=1, center_box=0, seed=12345, pair_variant=0, cell_size=0.0, use_graph=1,
-                 profile=0, slab=None, debug=0):
+                 profile=0, slab=None, debug=0, sort_every=0):
         """slab: None or dict(rank=, nranks=, rccl_id=bytes) or dict(rank=, nranks=, sendrecv=callable, allreduce=callable)."""
         L = lib()
         o = _Options()
@@ -270,6 +270,7 @@ class Engine:
         o.device, o.initial_forces, o.center_box, o.seed = device, initial_forces, center_box, seed
         o.pair_variant, o.cell_size, o.use_graph, o.profile = pair_variant, cell_size, use_graph, profile
         o.reserved[0] = debug
+        o.reserved[2] = sort_every          # 0: adaptive lazy re-sort (default), 1: rebuild the cells every step, n: at most every n-th step
         self.model = model
         self.N = int(model.query("n_atoms")[0])
         self.h = C.c_void_p()

@@ -32,6 +32,9 @@ struct CellBins
     int32_t perCell;              // bins reserved per cell; atoms beyond 16 * perCell of a cell are read from the per-atom arrays instead
 };
 
+// reference positions of the lazy re-sort: where every atom was when the cells were last rebuilt (sorted order); x == nullptr: not in use
+struct RefPos { double *x, *y, *z; };
+
 // species table, small enough to travel in the kernel-argument segment (scalar loads, no pointer chasing)
 struct SpecTable                  // cudaSpec, cuStruct.h:10-47
 {
@@ -125,6 +128,9 @@ struct StepParams
     int32_t rank, nranks;
     int32_t fuseKick;             // 1: the pair kernel also applies the second half-kick and books the kinetic energy (plain NVE steps)
     int32_t vdwFamily;            // pad1 == 2: the one potential type all defined species pairs share (1 lnjs, 2 buck, 3 p746, 4 bmhs)
+    double lazySlack2;            // lazy re-sort: square of the displacement an atom may have since the last sort ((hw * cell edge - rc) / 2 per axis, minimum);
+                                  // 0: the cells are rebuilt every step
+    double pruneR2;               // tile kernels: atoms farther than this (squared) from the centre cell's box are not staged: (rc + 2 slack)^2
     double ljDropR2;              // single_lj: r^2 beyond which |f| <= 1e5 is certain, so the 'pair dropped' rule (integrators.cpp:170) need not be evaluated
 };
 

@@ -60,8 +60,9 @@ private:
     void upload_bonded();
     void upload_ewald();
     void launch_ewald();
-    void sort_and_forces(bool integrate_first, bool withBonded = true);
+    void sort_and_forces(int stepMode, bool withBonded = true);   // 0: bin + sort + forces (aztot_forces), 1: a step that re-sorts, 2: a plain step of the lazy re-sort
     void launch_step_kernels();
+    void adapt_sort_interval();
     void launch_pair();
     int pair_variant() const;
     void exchange_halo();
@@ -101,6 +102,16 @@ private:
     char* dMsg_[4] = {nullptr, nullptr, nullptr, nullptr};   // sendLeft, sendRight, fromLeft, fromRight
     MsgLayout lay_{};
     int pairBlocks_ = 0, pairBlocksUsed_ = 0;
+    // lazy re-sort (one GPU): the cells are rebuilt only every lazyK_ steps; in between the atoms keep their slots, coordinates stay unwrapped and
+    // every step checks that no atom has moved farther than lazySlack_ from where it was sorted (RefPos) - see Engine::step
+    bool lazyOn_ = false;
+    int lazyK_ = 1;                 // current sort interval (1: every step); adapted after every aztot_step call from the largest step seen
+    int lazyCap_ = 32;
+    long long lazyViolations_ = 0;
+    int sinceSort_ = 1 << 30;       // plain steps since the last sort
+    double lazySlack_ = 0.0;
+    RefPos ref_{};
+    int graphCycle_ = 0;            // steps held by the captured graphs
     CellBins bins_{};               // per-cell bins of 16 atoms for pair kernel 3 (all-null when that kernel cannot run)
     BondedTables bonded_{};         // all-null when the model has no bonds / angles
     bool hasBonded_ = false;

@@ -335,6 +335,30 @@ void Engine::allocate()
             DevPot& d = pots[(size_t)a * ns + b];
             d.type = p.type; d.use_radii = p.use_radii; d.p0 = p.p0; d.p1 = p.p1; d.p2 = p.p2; d.p3 = p.p3; d.p4 = p.p4; d.r2cut = p.r2cut;
         }
+    {   // lazy re-sort: one GPU, no external field (its energy is booked from wrapped coordinates), not with pair kernel 3 (its bins are
+        // rebuilt by the sort), a stencil that can be widened by one cell on a violation, and a slack worth having
+        const Model& m = model_;
+        double slack = 1e300;
+        bool widenOk = true;
+        for (int k = 0; k < 3; k++)
+        {
+            slack = std::min(slack, 0.49 * (P_.hw[k] * P_.csz[k] - m.rMax));
+            if (P_.nc[k] < 2 * (P_.hw[k] + 1) + 1) widenOk = false;
+        }
+        const int sortEvery = opt_.reserved[2];                    // 0: adaptive, 1: every step (the reference's schedule), n: at most every n-th step
+        lazyOn_ = nranks_ == 1 && sortEvery != 1 && opt_.pair_variant != 3 && widenOk && m.rMax > 0 && slack > 1e-3 && m.E[0] == 0.0 && m.E[1] == 0.0 &&
+                  m.E[2] == 0.0 && pair_tile_supported(P_);
+        lazyCap_ = sortEvery > 1 ? std::min(sortEvery, 32) : 32;
+        if (lazyOn_ && (opt_.reserved[0] & 8192)) lazyK_ = lazyCap_;
+        lazySlack_ = lazyOn_ ? slack : 0.0;
+        P_.lazySlack2 = lazySlack_ * lazySlack_;
+        const double rp = m.rMax + 2.0 * lazySlack_;
+        P_.pruneR2 = rp * rp * (1.0 + 1e-12);
+        if (lazyOn_)
+        {
+            ref_.x = (double*)alloc(nd); ref_.y = (double*)alloc(nd); ref_.z = (double*)alloc(nd);
+        }
+    }
     {   // bins for pair kernel 3: only where it can run (stencil half-width 1, a specialised potential set, moderate density)
         const bool specialised = P_.single_lj || P_.pad1 == 2;
         const int perCell = pair_quad_bins_per_cell((double)capacity_ / std::max(1, P_.nCellLocal));
@@ -597,20 +621,31 @@ void Engine::exchange_halo()
 // ---------------------------------------------------------------------------------------------------
 // iter_fastCellList (cuPairs.cu:2519-2567): histogram -> [halo] -> scan -> sort -> pair forces
 // ---------------------------------------------------------------------------------------------------
-void Engine::sort_and_forces(bool integrate_first, bool withBonded)
+void Engine::sort_and_forces(int stepMode, bool withBonded)
 {
     const int gridAtoms = div_up(capacity_, kBlock);
+    const bool integrate_first = stepMode != 0;
+    if (stepMode == 2)
+    {   // plain step of the lazy re-sort: integrate only; slots, cells and buffers stay as they are
+        timed("integrate1", [&] {
+            hipLaunchKernelGGL(k_integrate1_bin<2>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
+                               dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1], dStats_, ref_);
+        });
+        sinceSort_++;
+    }
+    else
+    {
     if (integrate_first)
         timed("integrate1_bin", [&] {
-            hipLaunchKernelGGL(k_integrate1_bin<true>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
-                               dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1], dStats_);
+            hipLaunchKernelGGL(k_integrate1_bin<1>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
+                               dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1], dStats_, ref_);
         });
     else
     {
         HIP_CHECK(hipMemsetAsync(dCellCount_, 0, sizeof(int32_t) * (size_t)(nCellAlloc_ + 1), stream_));
         timed("bin", [&] {
-            hipLaunchKernelGGL(k_integrate1_bin<false>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
-                               dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1], dStats_);
+            hipLaunchKernelGGL(k_integrate1_bin<0>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
+                               dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1], dStats_, ref_);
         });
     }
     if (nranks_ > 1) exchange_halo();
@@ -631,9 +666,11 @@ void Engine::sort_and_forces(bool integrate_first, bool withBonded)
     });
     timed("rank_gather", [&] {
         hipLaunchKernelGGL(k_rank_gather, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellStart_, dTmpId_, dTmpSrc_, dTmpCell_, cur(), oth(),
-                           dCellOfSorted_, (P_.tstat == AZTOT_TSTAT_RADI || P_.use_radii || thermoTouched_) ? 2 : 0, P_, dCounts_, bonded_.idxOfId, bins_);
+                           dCellOfSorted_, (P_.tstat == AZTOT_TSTAT_RADI || P_.use_radii || thermoTouched_) ? 2 : 0, P_, dCounts_, bonded_.idxOfId, bins_, ref_);
     });
     cur_ ^= 1;
+    sinceSort_ = 0;
+    }
     launch_pair();
     if (hasEwald_) launch_ewald();
     if (hasBonded_ && withBonded)      // exec_bondlist + exec_anglelist, main.cpp:101-104 (GPU path: main.cu:307-312,353-363)
@@ -657,7 +694,7 @@ void Engine::collect_and_finalize(unsigned slotMask)
 
 void Engine::forces(bool withBonded)
 {
-    sort_and_forces(false, withBonded);
+    sort_and_forces(0, withBonded);
     // energies of this configuration; kinetic energy and wall counters are left untouched
     unsigned mask = (1u << PS_EVDW) | (1u << PS_ECOUL) | (1u << PS_DROPPED);
     if (hasBonded_ && withBonded) mask |= (1u << PS_EBOND) | (1u << PS_EANGLE);
@@ -678,7 +715,7 @@ void Engine::launch_step_kernels()
     // plain NVE steps leave integrate2 to somebody else (decided once, in the constructor): small systems / slabs -> the tile
     // kernel's epilogue (fuseEpilogue_); large ones -> the next step's k_integrate1_bin (lazyKick_, see finish_steps)
     fuseNow_ = fuseEpilogue_;
-    sort_and_forces(true);
+    sort_and_forces((lazyOn_ && sinceSort_ < lazyK_ - 1) ? 2 : 1);
     const bool fused = fuseNow_;                 // launch_pair drops the request if the tile kernel is not the one running
     fuseNow_ = false;
     ekinFromPair_ = fused;
@@ -732,39 +769,54 @@ void Engine::step(int nsteps)
 {
     if (nsteps <= 0) return;
     int done = 0;
+    // Lazy re-sort (one GPU): the reference rebuilds its cell list every step (main.cu:300-326); here a step re-sorts only every lazyK_-th time.  That is
+    // exact as long as no atom is farther than (stencil reach - rc) / 2 from where it was when the cells were built: every pair inside rc is then still
+    // found in the stencil of the cell the atoms were sorted into.  Plain steps leave slots, cells and buffers alone, keep coordinates unwrapped, count
+    // wall crossings when they happen, and check every atom's displacement; should one ever leave the slack (the interval is sized with a factor 2 to
+    // spare from the largest step seen), the pair kernels reach one cell further until the next sort - slower, still exact.  The first step of
+    // every call sorts (the deferred half-kick is re-armed by the scan).
+    sinceSort_ = 1 << 30;
+    const int K = lazyOn_ ? lazyK_ : 1;
+    const int cycle = (K == 1) ? 2 : K;          // steps per graph: the sort ping-pongs the buffers, so K = 1 takes two steps to come back
     // slab ranks: only with the loopback transport and only on request (debug bit 4096) - an experiment, see DESIGN.md section 6
     const bool slabGraph = nranks_ > 1 && ownedXch_ && (opt_.reserved[0] & 4096) && !(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE);
     const bool can_graph = opt_.use_graph && (nranks_ == 1 || slabGraph) && !profile_;
-    if (can_graph && nsteps >= 2)
+    if (can_graph && nsteps >= cycle)
     {
-        // a graph holds TWO consecutive steps (the sort ping-pongs between the two per-atom buffers), and there is
-        // one graph per starting buffer because kernel arguments are baked in at capture time
-        const int g = cur_;
-        if (!graphExec_[g])
+        // one graph per starting buffer because kernel arguments are baked in at capture time; a graph starts with a step that sorts
+        if (graphCycle_ != cycle) { destroy_graphs(); graphCycle_ = cycle; }
+        while (nsteps - done >= cycle)
         {
-            const int curBefore = cur_;
-            HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-            capturing_ = true;
-            try
+            const int g = cur_;
+            if (!graphExec_[g])
             {
-                launch_step_kernels();
-                launch_step_kernels();
-            }
-            catch (...)
-            {   // leave neither the stream in capture mode nor the engine believing it is capturing
-                hipGraph_t broken = nullptr;
-                (void)hipStreamEndCapture(stream_, &broken);
-                if (broken) (void)hipGraphDestroy(broken);
+                const int curBefore = cur_;
+                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                capturing_ = true;
+                try
+                {
+                    sinceSort_ = 1 << 30;
+                    for (int k = 0; k < cycle; k++) launch_step_kernels();
+                }
+                catch (...)
+                {   // leave neither the stream in capture mode nor the engine believing it is capturing
+                    hipGraph_t broken = nullptr;
+                    (void)hipStreamEndCapture(stream_, &broken);
+                    if (broken) (void)hipGraphDestroy(broken);
+                    capturing_ = false;
+                    cur_ = curBefore;
+                    throw;
+                }
                 capturing_ = false;
-                cur_ = curBefore;
-                throw;
+                HIP_CHECK(hipStreamEndCapture(stream_, &graph_[g]));
+                HIP_CHECK(hipGraphInstantiate(&graphExec_[g], graph_[g], nullptr, nullptr, 0));
+                cur_ = curBefore;                 // the capture itself executed nothing
             }
-            capturing_ = false;
-            HIP_CHECK(hipStreamEndCapture(stream_, &graph_[g]));
-            HIP_CHECK(hipGraphInstantiate(&graphExec_[g], graph_[g], nullptr, nullptr, 0));
-            // the capture itself executed nothing and left cur_ where it was
+            HIP_CHECK(hipGraphLaunch(graphExec_[g], stream_));
+            done += cycle;
+            if (K > 1) cur_ ^= 1;                 // one sort per cycle
+            sinceSort_ = 1 << 30;                 // the next cycle (or the eager remainder) starts with a sort
         }
-        while (nsteps - done >= 2) { HIP_CHECK(hipGraphLaunch(graphExec_[g], stream_)); done += 2; }
     }
     for (; done < nsteps; done++) launch_step_kernels();
     kickOwed_ = lazyKick_;          // set here, not in launch_step_kernels: a replayed graph does not pass through the host code
@@ -772,6 +824,45 @@ void Engine::step(int nsteps)
     check_launch("step kernels");
     sync();
     check_overflow();
+    if (lazyOn_) adapt_sort_interval();
+}
+
+// the largest step any atom made since the last look sizes the next calls' sort interval: K steps of that length use at most half the slack
+void Engine::adapt_sort_interval()
+{
+    Counts c;
+    HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
+    const unsigned long long zero = 0;
+    HIP_CHECK(hipMemcpy(&dCounts_->maxStep2, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    int K = lazyK_;
+    if (opt_.reserved[0] & 8192)
+    {   // debug: fixed interval whatever the speeds (exercises the wider-stencil fallback); violations are only counted
+        if (c.lazyViolatedEver)
+        {
+            const int32_t z = 0;
+            HIP_CHECK(hipMemcpy(&dCounts_->lazyViolatedEver, &z, sizeof(z), hipMemcpyHostToDevice));
+            lazyViolations_++;
+        }
+        K = lazyCap_;
+    }
+    else if (c.lazyViolatedEver)
+    {
+        const int32_t z = 0;
+        HIP_CHECK(hipMemcpy(&dCounts_->lazyViolatedEver, &z, sizeof(z), hipMemcpyHostToDevice));
+        K = std::max(1, K / 2);
+        lazyViolations_++;
+    }
+    else if (c.maxStep2 != 0)
+    {
+        double ms2;
+        std::memcpy(&ms2, &c.maxStep2, sizeof(ms2));
+        const double len = std::sqrt(ms2);
+        const double raw = len > 0 ? lazySlack_ / (2.0 * len) : 1e9;
+        static const int allowed[] = {32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
+        K = 1;
+        for (int a : allowed) if (a <= lazyCap_ && (double)a <= raw) { K = a; break; }
+    }
+    if (K != lazyK_) { lazyK_ = K; destroy_graphs(); graphCycle_ = 0; }
 }
 
 void Engine::check_overflow()
@@ -814,6 +905,7 @@ void Engine::get_stats(aztot_stats& out)
     out.pairs_dropped = (int64_t)v[17];
     out.n_cells = (int64_t)P_.nc[0] * P_.nc[1] * P_.nc[2];
     out.nose_chit = s.chit; out.nose_conint = s.conint;
+    out.sort_interval = lazyOn_ ? lazyK_ : 1; out.sort_violations = lazyViolations_;
     // pressure from the wall momentum over the window since the previous evaluation (main.cpp:143-163)
     if (s.step - lastPresStep_ >= std::max(1, model_.stat))
     {
@@ -860,6 +952,19 @@ void Engine::md_to_host(aztot_state& out)
     };
     AtomArrays& A = cur();
     down(out.x, A.x); down(out.y, A.y); down(out.z, A.z); down(out.vx, A.vx); down(out.vy, A.vy); down(out.vz, A.vz);
+    if (lazyOn_)
+    {   // between two sorts of a lazy run coordinates are kept unwrapped on the device: hand out what put_periodic would have left (box.cpp:230-295)
+        auto wrap = [](double x, double L) {
+            const double invL = 1.0 / L;
+            if (x < 0) x += ((int)(-x * invL) + 1) * L;
+            else if (x > L) x -= ((int)(x * invL)) * L;
+            return (x >= L) ? 0.0 : x;
+        };
+        double* arr[3] = {out.x, out.y, out.z};
+        for (int k = 0; k < 3; k++)
+            if (arr[k])
+                for (int q = 0; q < n; q++) arr[k][ids[q]] = wrap(arr[k][ids[q]], model_.L[k]);
+    }
     down(out.fx, A.fx); down(out.fy, A.fy); down(out.fz, A.fz); down(out.U, A.U); down(out.radius, A.rad);
     if (out.types)
     {

@@ -50,6 +50,21 @@ __device__ __forceinline__ double block_sum(double v, double* scratch)
     return r;
 }
 
+// maximum over the workgroup; result valid in thread 0
+__device__ __forceinline__ double block_max(double v, double* scratch)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, kWave));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) r = fmax(r, scratch[k]);
+    return r;
+}
+
 __device__ __forceinline__ void put_partial(double* partials, int maxBlocks, int slot, double v)
 {
     partials[(size_t)slot * maxBlocks + blockIdx.x] = v;
@@ -289,8 +304,17 @@ struct Counts
     int32_t nRecv;                  // atoms appended by k_unpack in the step in flight
     int32_t overflow;               // sticky: a fixed-capacity buffer was too small
     int32_t bondedMissing;          // sticky: a bond / angle partner was not resident on this rank (k_bonded)
-    int32_t reserved0;
+    int32_t lazyViolated;           // lazy re-sort: an atom has left the slack of its cell since the last sort (set by k_integrate1_bin on plain
+                                    // steps, cleared on sort steps): the pair kernels widen their stencil by one cell until the next sort
+    int32_t lazyViolatedEver;       // sticky copy for the host, which then shortens the sort interval
+    unsigned long long maxStep2;    // bit pattern of the largest |v dt|^2 of any atom since the host last looked (non-negative doubles order like integers)
 };
+
+// image index of a coordinate with exactly the case distinction of put_periodic / wrap_coord (box.cpp:243-252: x in [0, L] is image 0)
+__device__ __forceinline__ int image_of(double x, double L, double invL)
+{
+    return (x < 0) ? -((int)(-x * invL) + 1) : ((x > L) ? (int)(x * invL) : 0);
+}
 
 __device__ __forceinline__ int wave_append(bool flag, int32_t* counter)
 {   // position of this lane's element in a shared output list (one atomic per wave), -1 if the lane has nothing to append
@@ -308,25 +332,36 @@ __device__ __forceinline__ int wave_append(bool flag, int32_t* counter)
 // In slab mode the same kernel also packs this rank's message to each x-neighbour (slab.hip.h describes the protocol):
 // emigrants (full state) and the atoms of the hw boundary layers (position, type, id, radius), appended with one atomic per
 // wave and category.
-template <bool INTEGRATE>
+// STEPMODE 0: bin only (aztot_forces: wraps what a lazy run left unwrapped, counts nothing); 1: integrate + wrap + bin (a step that re-sorts:
+// every step unless the lazy re-sort is on); 2: integrate only (a plain step of the lazy re-sort: coordinates stay UNWRAPPED until the next sort,
+// wall crossings are still counted in the step they happen, and the displacement since the last sort is checked against the cells' slack)
+template <int STEPMODE>
 __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTable S, AtomArrays A, Counts* __restrict__ cnt,
                                                            int32_t* __restrict__ cellOf, int32_t* __restrict__ slotOf,
                                                            int32_t* __restrict__ cellCount, double* __restrict__ partials, int maxBlocks,
                                                            MsgLayout lay, char* __restrict__ sendLeft, char* __restrict__ sendRight,
-                                                           DevStats* __restrict__ st)
+                                                           DevStats* __restrict__ st, RefPos R0)
 {
+    constexpr bool INTEGRATE = STEPMODE != 0;
+    constexpr bool BIN = STEPMODE != 2;
     __shared__ double scratch[kBlock / kWave];
     const int begin = cnt->ownedBegin, end = cnt->ownedEnd;
     const int i = begin + blockIdx.x * kBlock + threadIdx.x;
     const bool pendingKick = INTEGRATE && st->pendingKick != 0;   // written only by kernels that run between two launches of this one
     if (INTEGRATE && blockIdx.x == 0 && threadIdx.x == 0) st->step += 1;   // the step in flight gets its 1-based number (main.cpp:92);
                                                                            // read only by the thermostat kernels at the end of the step
-    double eField = 0.0, mom[6] = {0, 0, 0, 0, 0, 0}, cross[6] = {0, 0, 0, 0, 0, 0};
-    int anyCross = 0, myCell = 0, myLayer = 0;
+    double eField = 0.0, mom[6] = {0, 0, 0, 0, 0, 0}, cross[6] = {0, 0, 0, 0, 0, 0}, stepLen2 = 0.0;
+    int anyCross = 0, myCell = 0, myLayer = 0, violated = 0;
+    if (STEPMODE == 1 && blockIdx.x == 0 && threadIdx.x == 0) cnt->lazyViolated = 0;      // the cells are rebuilt in this step
     if (i < end)
     {
         const int t = A.type[i];
         double x = A.x[i], y = A.y[i], z = A.z[i];
+        if (STEPMODE == 0 && P.lazySlack2 > 0.0)
+        {   // aztot_forces between two sorts of a lazy run: wrap first (crossings were counted when they happened)
+            wrap_coord(x, P.L[0], P.invL[0]); wrap_coord(y, P.L[1], P.invL[1]); wrap_coord(z, P.L[2], P.invL[2]);
+            A.x[i] = x; A.y[i] = y; A.z[i] = z;
+        }
         if (INTEGRATE)
         {
             const double rM = S.rMhdt[t], m = S.mass[t];
@@ -337,14 +372,25 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
             vx += rM * fxo;
             vy += rM * fyo;
             vz += rM * fzo;
-            if (!S.frozen[t]) { x += vx * P.dt; y += vy * P.dt; z += vz * P.dt; }
+            // a wall is crossed when the periodic image index changes (with every-step sorting the old index is 0 and this is put_periodic's
+            // own test); the coordinate itself is wrapped only on steps that re-sort
+            const int ix0 = image_of(x, P.L[0], P.invL[0]), iy0 = image_of(y, P.L[1], P.invL[1]), iz0 = image_of(z, P.L[2], P.invL[2]);
+            double dx = 0.0, dy = 0.0, dz = 0.0;
+            if (!S.frozen[t]) { dx = vx * P.dt; dy = vy * P.dt; dz = vz * P.dt; x += dx; y += dy; z += dz; }
+            stepLen2 = dx * dx + dy * dy + dz * dz;
             int c;
-            c = wrap_coord(x, P.L[0], P.invL[0]);
+            c = image_of(x, P.L[0], P.invL[0]) - ix0;
             if (c < 0) { mom[0] = m * (-vx); cross[0] = 1; anyCross = 1; } else if (c > 0) { mom[1] = m * vx; cross[1] = 1; anyCross = 1; }
-            c = wrap_coord(y, P.L[1], P.invL[1]);
+            c = image_of(y, P.L[1], P.invL[1]) - iy0;
             if (c < 0) { mom[2] = m * (-vy); cross[2] = 1; anyCross = 1; } else if (c > 0) { mom[3] = m * vy; cross[3] = 1; anyCross = 1; }
-            c = wrap_coord(z, P.L[2], P.invL[2]);
+            c = image_of(z, P.L[2], P.invL[2]) - iz0;
             if (c < 0) { mom[4] = m * (-vz); cross[4] = 1; anyCross = 1; } else if (c > 0) { mom[5] = m * vz; cross[5] = 1; anyCross = 1; }
+            if (BIN) { wrap_coord(x, P.L[0], P.invL[0]); wrap_coord(y, P.L[1], P.invL[1]); wrap_coord(z, P.L[2], P.invL[2]); }
+            else
+            {   // plain step: has the atom left the slack of the cell it was sorted into?
+                const double ex = x - R0.x[i], ey = y - R0.y[i], ez = z - R0.z[i];
+                if (ex * ex + ey * ey + ez * ez > P.lazySlack2) violated = 1;
+            }
             if (anyCross)
             {   // per-species crossing counters: specAcBoxNeg / specAcBoxPos of put_periodic (cuMDfunc.cu:35-106), the columns of
                 // msd.dat.  Crossings are rare (a few atoms per step), so plain global atomics cost nothing.
@@ -355,12 +401,25 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
             A.x[i] = x; A.y[i] = y; A.z[i] = z;
             eField = S.charge[t] * (x * P.E[0] + y * P.E[1] + z * P.E[2]);      // integrators.cpp:374 / cuMDfunc.cu:476
         }
-        int lx;
-        myCell = local_cell(P, x, y, z, &lx);
-        cellOf[i] = myCell;
-        myLayer = lx;
+        if (BIN)
+        {
+            int lx;
+            myCell = local_cell(P, x, y, z, &lx);
+            cellOf[i] = myCell;
+            myLayer = lx;
+        }
     }
-    if (P.nranks > 1)
+    if (INTEGRATE && P.lazySlack2 > 0.0)
+    {   // largest step of any atom (the host sizes the sort interval from it) and the violation flag: one atomic per workgroup at most
+        const double mx = block_max(stepLen2, scratch);
+        if (threadIdx.x == 0)
+        {   // thousands of workgroups on one word would serialise (~90 atomics per microsecond): look first, only a new maximum is published
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
+            if (bits > __hip_atomic_load(&cnt->maxStep2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cnt->maxStep2, bits);
+        }
+        if (!BIN && __syncthreads_or(violated) && threadIdx.x == 0) { cnt->lazyViolated = 1; cnt->lazyViolatedEver = 1; }
+    }
+    if (BIN && P.nranks > 1)
     {
         const bool live = i < end;
         const int hw = P.hw[0], lx = myLayer;
@@ -392,6 +451,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
             }
         }
     }
+    if (BIN)
     {
         // histogram with one atomic per RUN of equal cells inside the wave: the arrays are still in the previous
         // step's cell order, so neighbouring lanes mostly fall into the same cell (about 13 atoms per run)
@@ -551,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
                                                         const int32_t* __restrict__ tmpId, const int32_t* __restrict__ tmpSrc,
                                                         const int32_t* __restrict__ tmpCell, AtomArrays src, AtomArrays dst,
                                                         int32_t* __restrict__ cellOfSorted, int carryForces /* bit 0: forces, bit 1: U + radius */, StepParams P, Counts* cntOut,
-                                                        int32_t* __restrict__ idxOfId, CellBins B)
+                                                        int32_t* __restrict__ idxOfId, CellBins B, RefPos R0)
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p == 0)
@@ -574,6 +634,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
     const int i = tmpSrc[p];
     const double x = src.x[i], y = src.y[i], z = src.z[i];
     dst.x[d] = x; dst.y[d] = y; dst.z[d] = z;
+    if (R0.x) { R0.x[d] = x; R0.y[d] = y; R0.z[d] = z; }         // lazy re-sort: displacements are measured from here
     if (B.x)
     {   // the same atom in its cell's bins, relative to the centre of the cell it was binned into (count_cell: floor(x * cRevSize))
         if (rank < 16 * B.perCell)
@@ -613,6 +674,8 @@ __global__ __launch_bounds__(kBlock) void k_pair_atom(StepParams P, SpecTable S,
     __shared__ double scratch[kBlock / kWave];
     const int i = cnt->ownedBegin + blockIdx.x * kBlock + threadIdx.x;
     PairAcc acc = {0, 0, 0, 0, 0, 0};
+    if (cnt->lazyViolated)
+        for (int k = 0; k < 3; k++) { P.hw[k] += 1; P.nOff[k] = min(2 * P.hw[k] + 1, P.nc[k]); }     // an atom has left its cell's slack: reach one cell further
     if (i < cnt->ownedEnd)
     {
         const double xi = A.x[i], yi = A.y[i], zi = A.z[i];

@@ -320,8 +320,12 @@ template <int MODE, int VDW>   // 0: generic (any mix, radii) ; 1: one species, 
                       // 3: as 2 with the real-space term of the Ewald sum ; 4: one species, surk with thermostat radii (case study 2)
 __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
-                                                     double* __restrict__ partials, int maxBlocks)
+                                                     double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts)
 {
+    // lazy re-sort (Engine::step): an atom has left the slack of the cell it was sorted into - until the next sort the stencil reaches one cell
+    // further (rare; Engine::lazy_allowed guarantees that the wider stencil still sees every cell through one image only)
+    if (P.lazySlack2 > 0.0 && counts->lazyViolated)
+        for (int k = 0; k < 3; k++) { P.hw[k] += 1; P.nOff[k] = 2 * P.hw[k] + 1; }
     constexpr bool kOneSpecies = (MODE == 1 || MODE == 4);           // no species table, no type ids
     __shared__ double txyz[3 * kTileLds];                            // candidate coordinates RELATIVE to the centre of the centre cell
     __shared__ float tw[kTileLds];                                   // -(x^2 + y^2 + z^2) of the same, f32: 4th operand row of the filter
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
         const double cc0 = (lx + P.cx0) * P.csz[0] + h0, cc1 = cy * P.csz[1] + h1, cc2 = cz * P.csz[2] + h2;
         // f32 filter threshold: rc^2 + error bound.  Operands are rounded to f32 (2^-24 relative), products and the 4-term sum are f32:
         // |error| <= 2^-21 (|ri|^2 + |rj|^2 + 2 |ri.rj| + rc^2) with |r|^2 <= sum (h + rc)^2 - bounded here with a factor 4 to spare
-        const double rcut = sqrt(P.r2Max);
+        const double rprune = sqrt(P.pruneR2), rcut = rprune + 0.5 * (rprune - sqrt(P.r2Max));     // staged atoms reach rc + 2 slack from the box, the cell's own atoms slack
         const double ext2 = (h0 + rcut) * (h0 + rcut) + (h1 + rcut) * (h1 + rcut) + (h2 + rcut) * (h2 + rcut);
         const double filtThr = P.r2Max + 1.9073486328125e-06 * (4.0 * ext2 + P.r2Max);      // 2^-19
         const DevPot lj = pots[0];
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                                 const double bx = fmax(fabs(xj) - h0, 0.0);
                                 const double by = fmax(fabs(yj) - h1, 0.0);
                                 const double bz = fmax(fabs(zj) - h2, 0.0);
-                                const bool keep = (lane < gjn[u]) && (bx * bx + by * by + bz * bz) <= P.r2Max * (1.0 + 1e-12);
+                                const bool keep = (lane < gjn[u]) && (bx * bx + by * by + bz * bz) <= P.pruneR2;
                                 const unsigned long long mask = __ballot(keep);
                                 if (keep)
                                 {
@@ -574,36 +578,36 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
 }
 
 template <int MODE, int VDW>
-inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const int32_t* cellStart, double* partials,
+inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
                                 int maxBlocks, hipStream_t stream)
 {
     const int nRun = pair_tile_cells(P);
     const int plane = P.nc[1] * P.nc[2];
     const int first = (P.nranks > 1) ? P.hw[0] * plane : 0;
-    hipLaunchKernelGGL((k_pair_tile<MODE, VDW>), dim3(pair_tile_grid(P)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks);
+    hipLaunchKernelGGL((k_pair_tile<MODE, VDW>), dim3(pair_tile_grid(P)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks, cnt);
 }
 
 // P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs; 5 = a mix of them,
 // selected per species pair), <= 4 species, no radii,
 // electrostatics none / direct / Fennell / Ewald with alpha rReal <= 4 (Engine::Engine decides)
-inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts*, const int32_t* cellStart,
+inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
                              double* partials, int maxBlocks, hipStream_t stream)
 {
-    if (P.single_lj) { launch_pair_tile_as<1, 1>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return; }
-    if (P.pad1 == 4) { launch_pair_tile_as<4, 7>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return; }     // one species, surk + radii
+    if (P.single_lj) { launch_pair_tile_as<1, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return; }
+    if (P.pad1 == 4) { launch_pair_tile_as<4, 7>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return; }     // one species, surk + radii
     if (P.pad1 == 2)
     {
         const bool ew = P.elec_type == 2;
         switch (P.vdwFamily)
         {
-        case 1: if (ew) launch_pair_tile_as<3, 1>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 1>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
-        case 2: if (ew) launch_pair_tile_as<3, 2>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 2>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
-        case 3: if (ew) launch_pair_tile_as<3, 3>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 3>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
-        case 4: if (ew) launch_pair_tile_as<3, 4>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 4>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
-        case 5: if (ew) launch_pair_tile_as<3, 5>(P, S, pots, A, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 5>(P, S, pots, A, cellStart, partials, maxBlocks, stream); return;
+        case 1: if (ew) launch_pair_tile_as<3, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return;
+        case 2: if (ew) launch_pair_tile_as<3, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return;
+        case 3: if (ew) launch_pair_tile_as<3, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return;
+        case 4: if (ew) launch_pair_tile_as<3, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return;
+        case 5: if (ew) launch_pair_tile_as<3, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return;
         }
     }
-    launch_pair_tile_as<0, 0>(P, S, pots, A, cellStart, partials, maxBlocks, stream);
+    launch_pair_tile_as<0, 0>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream);
 }
 
 }  // namespace aztot

@@ -132,9 +132,13 @@ typedef struct
     int32_t use_graph;           /* 1: replay the step as a captured hipGraph when possible */
     int32_t profile;             /* 1: time every kernel with HIP events (aztot_kernel_times) */
     int32_t reserved[8];         /* [0]: path switches for A/B measurements, results unchanged (128: k_integrate2 every step, 256: large-system
-                                    kick path, 512: generic pair kernel, 4096: hipGraph replay of a loopback slab rank) - and one that is NOT
+                                    kick path, 512: generic pair kernel, 4096: hipGraph replay of a loopback slab rank, 8192: lazy re-sort at the fixed interval reserved[2] whatever the atoms' speed -
+                                    exercises the wider-stencil fallback) - and one that is NOT
                                     result-preserving: 2048 = the pair kernel stages its tile and stops (phase timing only);
-                                    [1]: 1 = loopback slab transport (one rank of N talks to itself: timing aid) */
+                                    [1]: 1 = loopback slab transport (one rank of N talks to itself: timing aid);
+                                    [2]: cell-list rebuild schedule on one GPU.  0 (default): adaptive - a step re-sorts only when an atom could have left the
+                                    slack between the stencil's reach and the cut-off (exact; the reference rebuilds every step, main.cu:300-326, and results then
+                                    differ from an every-step run in summation order only); 1: every step; n > 1: adaptive, at most every n-th step */
 } aztot_options;
 
 /* per-step scalars: the fields tracked by stat.dat (cuStat.cu:241-261) + serial calc_chars (integrators.cpp:63-73) */
@@ -153,6 +157,8 @@ typedef struct
     double engBond, engAngle;    /* exec_bondlist bonds.cpp:1218, exec_anglelist angles.cpp:240; both are part of engTot */
     double engCoulRec, engCoulConst; /* Ewald sum: reciprocal part (engElec2, elec.cpp:333 ; cudaMD::engCoul2) and constant part
                                         (engElec1, ewald_const elec.cpp:144 ; engCoul3); engCoul above is the real-space part */
+    int64_t sort_interval;       /* steps between two rebuilds of the cell list that the next aztot_step call will use (1: every step) */
+    int64_t sort_violations;     /* calls so far in which an atom left its cell's slack before the scheduled rebuild (handled exactly, by a wider stencil) */
 } aztot_stats;
 
 /* host copy of the per-atom state, fp64 SoA, in ORIGINAL atom order (id order); any pointer may be NULL */

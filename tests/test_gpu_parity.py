@@ -494,6 +494,42 @@ def test_second_half_kick_ownership(variant):
     assert abs(kin[-1] - o.stats()["engKin"]) < 1e-11 * kin[-1]
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("mode", ["adaptive", "forced"])
+def test_lazy_resort_is_exact(mode, variant):
+    """lazy re-sort against the every-step schedule and the oracle on a hot liquid (3 000 K: atoms cross walls and change cells all the time).
+    'adaptive': the default - the interval follows the largest step seen.  'forced': debug bit 8192 holds the interval at 32 steps although the atoms
+    are far too fast for it, so atoms DO leave their cell's slack between sorts and the pair kernels fall back to the wider stencil - the result must
+    not change.  60 steps in five calls; x / v / f 1e-9 against the oracle, wall counters and per-species crossings equal."""
+    case = inputs.lj_case((7, 7, 7), a=5.4, seed=23, rc=6.5, cell_list=6.9, vel_T=3000.0 if mode == "adaptive" else 9000.0)
+    case["dt"] = 0.001 if mode == "adaptive" else 0.002           # 'forced': 0.05 A per step against a slack of 0.52 A, held for 32 steps
+    kw = dict(sort_every=32, debug=8192) if mode == "forced" else {}
+    a = engine(case, pair_variant=variant, **kw)
+    b = engine(case, pair_variant=variant, sort_every=1)
+    o = oracle.Oracle(case)
+    o.forces(1)
+    for n in (1, 9, 20, 25, 5):
+        a.step(n); b.step(n); o.step(n)
+    sa, sb, so, sta, stb, sto = a.state(), b.state(), o.state(), a.stats(), b.stats(), o.stats()
+    if mode == "forced":
+        assert sta["sort_interval"] == 32 and sta["sort_violations"] > 0
+    else:
+        assert sta["sort_violations"] == 0
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(sa[k], sb[k]) < 1e-9, (k, rel_err(sa[k], sb[k]))
+        assert rel_err(sa[k], so[k]) < 1e-9, (k, rel_err(sa[k], so[k]))
+    assert sta["negCross"] + sta["posCross"] == stb["negCross"] + stb["posCross"] == [sto["cross"][k] for k in (0, 2, 4, 1, 3, 5)]
+    assert np.array_equal(a.species_crossings(), b.species_crossings())
+    assert rel_err(sta["negMom"] + sta["posMom"], stb["negMom"] + stb["posMom"]) < 1e-10
+    for k in ("engVdW", "engKin", "engTot"):
+        assert abs(sta[k] - stb[k]) <= 1e-10 * abs(stb[k]), (k, sta[k], stb[k])
+    a.forces()                                  # a force call between two sorts wraps and re-sorts without touching the counters
+    s2 = a.state()
+    for k in FKEYS:
+        assert rel_err(s2[k], sb[k]) < 1e-10
+    assert a.stats()["posCross"] == sta["posCross"]
+
+
 def test_tile_and_atom_kernels_agree_bitwise_on_energy_scale():
     case = inputs.config("F3")
     a, b = engine(case, pair_variant=1), engine(case, pair_variant=2)
