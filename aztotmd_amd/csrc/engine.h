@@ -63,6 +63,7 @@ private:
     void sort_and_forces(int stepMode, bool withBonded = true);   // 0: bin + sort + forces (aztot_forces), 1: a step that re-sorts, 2: a plain step of the lazy re-sort
     void launch_step_kernels();
     void adapt_sort_interval();
+    void run_steps(int nsteps);
     void launch_pair();
     int pair_variant() const;
     void exchange_halo();
@@ -108,6 +109,7 @@ private:
     int lazyK_ = 1;                 // current sort interval (1: every step); adapted after every aztot_step call from the largest step seen
     int lazyCap_ = 32;
     long long lazyViolations_ = 0;
+    bool lazyMeasured_ = false;     // the interval has been sized from a measurement at least once
     int sinceSort_ = 1 << 30;       // plain steps since the last sort
     double lazySlack_ = 0.0;
     RefPos ref_{};

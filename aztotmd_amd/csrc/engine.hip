@@ -350,6 +350,9 @@ void Engine::allocate()
                   m.E[2] == 0.0 && pair_tile_supported(P_);
         lazyCap_ = sortEvery > 1 ? std::min(sortEvery, 32) : 32;
         if (lazyOn_ && (opt_.reserved[0] & 8192)) lazyK_ = lazyCap_;
+        // no more than 1.2 % of the cut-off: the tile kernels stage everything within rc + 2 slack of a cell, and a sort interval of 32 steps needs
+        // no more than that at liquid speeds (small cells would otherwise offer A of slack and pay for it in candidates: S40 +16 % pair time)
+        slack = std::min(slack, 0.012 * m.rMax);
         lazySlack_ = lazyOn_ ? slack : 0.0;
         P_.lazySlack2 = lazySlack_ * lazySlack_;
         const double rp = m.rMax + 2.0 * lazySlack_;
@@ -768,6 +771,26 @@ void Engine::finish_steps()
 void Engine::step(int nsteps)
 {
     if (nsteps <= 0) return;
+    // the sort interval is re-evaluated every 256 steps of a long call (and once after the first 8 steps an engine ever makes, so that even a
+    // single call benefits): a stream synchronisation and a 48-byte read-back
+    int left = nsteps;
+    while (left > 0)
+    {
+        const int n = lazyOn_ ? std::min(left, lazyMeasured_ ? 256 : 8) : left;
+        run_steps(n);
+        left -= n;
+        if (left > 0) { sync(); adapt_sort_interval(); }
+    }
+    kickOwed_ = lazyKick_;          // set here, not in launch_step_kernels: a replayed graph does not pass through the host code
+    finish_steps();
+    check_launch("step kernels");
+    sync();
+    check_overflow();
+    if (lazyOn_) adapt_sort_interval();
+}
+
+void Engine::run_steps(int nsteps)
+{
     int done = 0;
     // Lazy re-sort (one GPU): the reference rebuilds its cell list every step (main.cu:300-326); here a step re-sorts only every lazyK_-th time.  That is
     // exact as long as no atom is farther than (stencil reach - rc) / 2 from where it was when the cells were built: every pair inside rc is then still
@@ -819,12 +842,6 @@ void Engine::step(int nsteps)
         }
     }
     for (; done < nsteps; done++) launch_step_kernels();
-    kickOwed_ = lazyKick_;          // set here, not in launch_step_kernels: a replayed graph does not pass through the host code
-    finish_steps();
-    check_launch("step kernels");
-    sync();
-    check_overflow();
-    if (lazyOn_) adapt_sort_interval();
 }
 
 // the largest step any atom made since the last look sizes the next calls' sort interval: K steps of that length use at most half the slack
@@ -834,6 +851,7 @@ void Engine::adapt_sort_interval()
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
     const unsigned long long zero = 0;
     HIP_CHECK(hipMemcpy(&dCounts_->maxStep2, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    lazyMeasured_ = true;
     int K = lazyK_;
     if (opt_.reserved[0] & 8192)
     {   // debug: fixed interval whatever the speeds (exercises the wider-stencil fallback); violations are only counted

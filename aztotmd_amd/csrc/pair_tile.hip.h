@@ -324,8 +324,12 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
 {
     // lazy re-sort (Engine::step): an atom has left the slack of the cell it was sorted into - until the next sort the stencil reaches one cell
     // further (rare; Engine::lazy_allowed guarantees that the wider stencil still sees every cell through one image only)
-    if (P.lazySlack2 > 0.0 && counts->lazyViolated)
+    const bool widened = P.lazySlack2 > 0.0 && counts->lazyViolated;
+    if (widened)
+    {   // nothing is known about how far the atoms have strayed beyond the slack (less than a cell, the host halves the interval at once): no pruning
         for (int k = 0; k < 3; k++) { P.hw[k] += 1; P.nOff[k] = 2 * P.hw[k] + 1; }
+        P.pruneR2 = 1e300;
+    }
     constexpr bool kOneSpecies = (MODE == 1 || MODE == 4);           // no species table, no type ids
     __shared__ double txyz[3 * kTileLds];                            // candidate coordinates RELATIVE to the centre of the centre cell
     __shared__ float tw[kTileLds];                                   // -(x^2 + y^2 + z^2) of the same, f32: 4th operand row of the filter
@@ -357,7 +361,12 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
         // f32 filter threshold: rc^2 + error bound.  Operands are rounded to f32 (2^-24 relative), products and the 4-term sum are f32:
         // |error| <= 2^-21 (|ri|^2 + |rj|^2 + 2 |ri.rj| + rc^2) with |r|^2 <= sum (h + rc)^2 - bounded here with a factor 4 to spare
         const double rprune = sqrt(P.pruneR2), rcut = rprune + 0.5 * (rprune - sqrt(P.r2Max));     // staged atoms reach rc + 2 slack from the box, the cell's own atoms slack
-        const double ext2 = (h0 + rcut) * (h0 + rcut) + (h1 + rcut) * (h1 + rcut) + (h2 + rcut) * (h2 + rcut);
+        double ext2 = (h0 + rcut) * (h0 + rcut) + (h1 + rcut) * (h1 + rcut) + (h2 + rcut) * (h2 + rcut);
+        if (widened)
+        {   // unpruned: candidates sit anywhere in the (widened) stencil
+            const double w0 = (2 * P.hw[0] + 1) * h0, w1 = (2 * P.hw[1] + 1) * h1, w2 = (2 * P.hw[2] + 1) * h2;
+            ext2 = w0 * w0 + w1 * w1 + w2 * w2;
+        }
         const double filtThr = P.r2Max + 1.9073486328125e-06 * (4.0 * ext2 + P.r2Max);      // 2^-19
         const DevPot lj = pots[0];
         if (MODE == 2 || MODE == 3)

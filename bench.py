@@ -30,7 +30,8 @@ FP64_VECTOR_PEAK = 78.6e12   # FLOP/s, FP64 vector (256 CUs x 128 FLO
 PAIR_BYTES_PER_ATOM = 52.0   # x,y,z,type read + fx,fy,fz written
 PAIR_BYTES_PER_CELL = 8.0    # cellStart/cellCount
 # algorithmic bytes per atom of the streaming kernels: the ones for which ">= 40 % of HBM peak" is the meaningful target
-STREAM_BYTES_PER_ATOM = {"integrate1_bin": 132.0, "place": 28.0, "rank_gather": 120.0, "integrate2": 76.0, "post_tstat": 84.0}
+STREAM_BYTES_PER_ATOM = {"integrate1_bin": 132.0, "integrate1": 148.0, "place": 28.0, "rank_gather": 144.0, "integrate2": 76.0, "post_tstat": 84.0}
+# (integrate1 = a plain step of the lazy re-sort: no cell id / slot written (-8), reference position read (+24); rank_gather also writes that reference (+24))
 
 
 def parse():
@@ -41,6 +42,7 @@ def parse():
     ap.add_argument("--workload", default="C4", help="C4 (1 000 188 Ar LJ, default), C3 (+Fennell Coulomb), C2 (40 000 Ar LJ), M4 (1 029 000 atoms in bonded triatomics)")
     ap.add_argument("--pair-variant", type=int, default=0)
     ap.add_argument("--cell-size", type=float, default=0.0)
+    ap.add_argument("--sort-every", type=int, default=0, help="cell-list rebuild schedule: 0 adaptive lazy re-sort (default), 1 every step (the reference's), n at most every n-th step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline sample (0: sized for ~15 s)")
     ap.add_argument("--debug", type=int, default=0,
@@ -137,7 +139,7 @@ def main():
     transport = "single GPU"
     try:
         eng = api.Engine(model, device=local_rank, initial_forces=1, pair_variant=a.pair_variant, cell_size=a.cell_size,
-                         use_graph=1, profile=0, slab=slab, debug=a.debug)
+                         use_graph=1, profile=0, slab=slab, debug=a.debug, sort_every=a.sort_every)
         if world > 1:
             transport = "RCCL send/recv over xGMI"
         if a.emulate_ranks > 1:
@@ -229,7 +231,7 @@ def main():
                                     "S4": "4 000 atoms, surk rc 6.0 + radii on 2.7 A cells, radiative thermostat 500 K (periodic analogue of case study 2)",
                                     "S40": "40 000 atoms, surk rc 6.0 + radii on 2.7 A cells, radiative thermostat 500 K"}.get(a.workload, a.workload),
                        "n_atoms": n_atoms, "n_cells": st["n_cells"], "decomposition": "single GPU" if world == 1 else "%d slabs along x" % world, "transport": transport, "rccl_ranks": rccl_ranks, "ranks_share_gpus": oversubscribed,
-                       "pair_variant": a.pair_variant,
+                       "pair_variant": a.pair_variant, "sort_interval": st.get("sort_interval"), "sort_violations": st.get("sort_violations"),
                        "kernel_timing": "second pass of the same %d steps with HIP events on the engine stream" % a.steps if profile else "off"},
             "matom_steps_per_s": n_atoms * a.steps / wall / 1e6,
             "ms_per_step_with_events": (wall_events / a.steps * 1e3) if wall_events else None,

@@ -502,7 +502,7 @@ def test_lazy_resort_is_exact(mode, variant):
     are far too fast for it, so atoms DO leave their cell's slack between sorts and the pair kernels fall back to the wider stencil - the result must
     not change.  60 steps in five calls; x / v / f 1e-9 against the oracle, wall counters and per-species crossings equal."""
     case = inputs.lj_case((7, 7, 7), a=5.4, seed=23, rc=6.5, cell_list=6.9, vel_T=3000.0 if mode == "adaptive" else 9000.0)
-    case["dt"] = 0.001 if mode == "adaptive" else 0.002           # 'forced': 0.05 A per step against a slack of 0.52 A, held for 32 steps
+    case["dt"] = 0.001 if mode == "adaptive" else 0.002           # 'forced': up to 0.05 A per step against a slack of 0.08 A, held for 32 steps
     kw = dict(sort_every=32, debug=8192) if mode == "forced" else {}
     a = engine(case, pair_variant=variant, **kw)
     b = engine(case, pair_variant=variant, sort_every=1)
