@@ -113,6 +113,7 @@ private:
     int sinceSort_ = 1 << 30;       // plain steps since the last sort
     double lazySlack_ = 0.0;
     RefPos ref_{};
+    int halo_[5] = {0, 0, 0, 0, 0};  // slab ranks: ownedBegin, end of the left boundary layers, start of the right ones, ownedEnd, nTotal (after the last sort)
     int graphCycle_ = 0;            // steps held by the captured graphs
     CellBins bins_{};               // per-cell bins of 16 atoms for pair kernel 3 (all-null when that kernel cannot run)
     BondedTables bonded_{};         // all-null when the model has no bonds / angles

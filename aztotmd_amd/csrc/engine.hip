@@ -346,7 +346,8 @@ void Engine::allocate()
             if (P_.nc[k] < 2 * (P_.hw[k] + 1) + 1) widenOk = false;
         }
         const int sortEvery = opt_.reserved[2];                    // 0: adaptive, 1: every step (the reference's schedule), n: at most every n-th step
-        lazyOn_ = nranks_ == 1 && sortEvery != 1 && opt_.pair_variant != 3 && widenOk && m.rMax > 0 && slack > 1e-3 && m.E[0] == 0.0 && m.E[1] == 0.0 &&
+        // (a slab rank cannot widen its stencil - it holds hw ghost layers - so there a violation is an error and the interval keeps a factor 4 in hand)
+        lazyOn_ = sortEvery != 1 && opt_.pair_variant != 3 && (widenOk || nranks_ > 1) && m.rMax > 0 && slack > 1e-3 && m.E[0] == 0.0 && m.E[1] == 0.0 &&
                   m.E[2] == 0.0 && pair_tile_supported(P_);
         lazyCap_ = sortEvery > 1 ? std::min(sortEvery, 32) : 32;
         if (lazyOn_ && (opt_.reserved[0] & 8192)) lazyK_ = lazyCap_;
@@ -634,6 +635,16 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
             hipLaunchKernelGGL(k_integrate1_bin<2>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
                                dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1], dStats_, ref_);
         });
+        if (nranks_ > 1)
+        {   // the neighbours hold this rank's boundary atoms in the order of the last sort: only their coordinates (and radii) travel
+            const int left = (rank_ + nranks_ - 1) % nranks_, right = (rank_ + 1) % nranks_;
+            AtomArrays& A = cur();
+            double* arr[4] = {A.x, A.y, A.z, A.rad};
+            timed("exchange_coords", [&] {
+                xch_->exchange_ranges(left, right, arr, P_.use_radii ? 4 : 3, halo_[0], halo_[1] - halo_[0], halo_[2], halo_[3] - halo_[2], 0, halo_[0], halo_[3],
+                                      halo_[4] - halo_[3], stream_);
+            });
+        }
         sinceSort_++;
     }
     else
@@ -673,6 +684,18 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
     });
     cur_ ^= 1;
     sinceSort_ = 0;
+    if (nranks_ > 1 && lazyOn_ && lazyK_ > 1)
+    {   // where the boundary layers sit in the sorted arrays: [ownedBegin, end of layer 2hw-1) goes left, [start of layer ncx-2hw, ownedEnd) goes right;
+        // ghosts are [0, ownedBegin) and [ownedEnd, nTotal).  One small read-back per sort.
+        const int plane = P_.nc[1] * P_.nc[2], hw = P_.hw[0];
+        int32_t v[2];
+        Counts c;
+        HIP_CHECK(hipMemcpyAsync(&v[0], dCellStart_ + (size_t)2 * hw * plane, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipMemcpyAsync(&v[1], dCellStart_ + (size_t)(P_.ncxLocal - 2 * hw) * plane, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipMemcpyAsync(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        halo_[0] = c.ownedBegin; halo_[1] = v[0]; halo_[2] = v[1]; halo_[3] = c.ownedEnd; halo_[4] = c.nTotal;
+    }
     }
     launch_pair();
     if (hasEwald_) launch_ewald();
@@ -849,6 +872,28 @@ void Engine::adapt_sort_interval()
 {
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
+    if (nranks_ > 1)
+    {   // every rank must arrive at the same interval (sort steps carry the full exchange) and at the same verdict: one slot per rank + the flag
+        double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double mine;
+        std::memcpy(&mine, &c.maxStep2, sizeof(mine));
+        if (nranks_ <= 8) v[rank_] = mine; else v[0] = 0.0;
+        v[8] = c.lazyViolatedEver ? 1.0 : 0.0;
+        v[9] = nranks_ > 8 ? mine : 0.0;              // more than 8 ranks: sum of squares bounds the maximum from above (conservative)
+        xch_->allreduce_sum(v, 10, stream_);
+        double mx = v[9];
+        for (int k = 0; k < 8; k++) mx = std::max(mx, v[k]);
+        std::memcpy(&c.maxStep2, &mx, sizeof(mx));
+        c.lazyViolatedEver = v[8] > 0.0 ? 1 : 0;
+        if (c.lazyViolatedEver)
+        {
+            const int32_t z = 0;
+            HIP_CHECK(hipMemcpy(&dCounts_->lazyViolatedEver, &z, sizeof(z), hipMemcpyHostToDevice));
+            lazyK_ = 1; lazyMeasured_ = false; lazyViolations_++;
+            throw std::runtime_error("lazy re-sort on slab ranks: an atom left its cell's slack between two sorts (the speeds grew more than fourfold within one "
+                                     "interval); the forces of this call are not exact - restart from the last state with options.reserved[2] = 1");
+        }
+    }
     const unsigned long long zero = 0;
     HIP_CHECK(hipMemcpy(&dCounts_->maxStep2, &zero, sizeof(zero), hipMemcpyHostToDevice));
     lazyMeasured_ = true;
@@ -875,7 +920,7 @@ void Engine::adapt_sort_interval()
         double ms2;
         std::memcpy(&ms2, &c.maxStep2, sizeof(ms2));
         const double len = std::sqrt(ms2);
-        const double raw = len > 0 ? lazySlack_ / (2.0 * len) : 1e9;
+        const double raw = len > 0 ? lazySlack_ / ((nranks_ > 1 ? 4.0 : 2.0) * len) : 1e9;
         static const int allowed[] = {32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
         K = 1;
         for (int a : allowed) if (a <= lazyCap_ && (double)a <= raw) { K = a; break; }

@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -31,6 +32,32 @@ void CallbackExchanger::exchange(int left, int right, const void* dSendLeft, con
         throw std::runtime_error("slab exchange callback failed (rightward)");
     HIP_CHECK(hipMemcpyAsync(dFromLeft, hr_[0].data(), bytes, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(dFromRight, hr_[1].data(), bytes, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void CallbackExchanger::exchange_ranges(int left, int right, double* const* arrays, int nArr, int sLb, int sLn, int sRb, int sRn, int rLb, int rLn,
+                                        int rRb, int rRn, hipStream_t stream)
+{
+    const size_t bsL = sizeof(double) * (size_t)nArr * sLn, bsR = sizeof(double) * (size_t)nArr * sRn;
+    const size_t brL = sizeof(double) * (size_t)nArr * rLn, brR = sizeof(double) * (size_t)nArr * rRn;
+    hs_[0].resize(std::max<size_t>(bsL, 8)); hs_[1].resize(std::max<size_t>(bsR, 8)); hr_[0].resize(std::max<size_t>(brL, 8)); hr_[1].resize(std::max<size_t>(brR, 8));
+    for (int a = 0; a < nArr; a++)
+    {
+        if (sLn) HIP_CHECK(hipMemcpyAsync(hs_[0].data() + sizeof(double) * (size_t)a * sLn, arrays[a] + sLb, sizeof(double) * (size_t)sLn, hipMemcpyDeviceToHost, stream));
+        if (sRn) HIP_CHECK(hipMemcpyAsync(hs_[1].data() + sizeof(double) * (size_t)a * sRn, arrays[a] + sRb, sizeof(double) * (size_t)sRn, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+    int64_t got = 0;
+    // leftward messages first (everyone sends left / receives from the right), then rightward ones - as in exchange()
+    if (sr_(ctx_, left, hs_[0].data(), (int64_t)bsL, right, hr_[1].data(), (int64_t)brR, &got) != 0 || got != (int64_t)brR)
+        throw std::runtime_error("slab coordinate exchange failed (leftward): the neighbours disagree about their boundary atoms");
+    if (sr_(ctx_, right, hs_[1].data(), (int64_t)bsR, left, hr_[0].data(), (int64_t)brL, &got) != 0 || got != (int64_t)brL)
+        throw std::runtime_error("slab coordinate exchange failed (rightward): the neighbours disagree about their boundary atoms");
+    for (int a = 0; a < nArr; a++)
+    {
+        if (rLn) HIP_CHECK(hipMemcpyAsync(arrays[a] + rLb, hr_[0].data() + sizeof(double) * (size_t)a * rLn, sizeof(double) * (size_t)rLn, hipMemcpyHostToDevice, stream));
+        if (rRn) HIP_CHECK(hipMemcpyAsync(arrays[a] + rRb, hr_[1].data() + sizeof(double) * (size_t)a * rRn, sizeof(double) * (size_t)rRn, hipMemcpyHostToDevice, stream));
+    }
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
@@ -76,6 +103,38 @@ void LoopbackExchanger::exchange(int, int, const void* dSendLeft, const void* dS
     const int n = (int)((bytes - haloOff_) / haloStride_ + (haloOff_ - migOff_) / migStride_);
     hipLaunchKernelGGL(k_loopback_shift, dim3((n + 255) / 256), dim3(256), 0, stream, (char*)dFromRight, migOff_, haloOff_, migStride_, haloStride_, w_, L_);
     hipLaunchKernelGGL(k_loopback_shift, dim3((n + 255) / 256), dim3(256), 0, stream, (char*)dFromLeft, migOff_, haloOff_, migStride_, haloStride_, -w_, L_);
+}
+
+// one kernel for the whole loopback coordinate exchange (a grouped ncclSend/ncclRecv is one operation too): what goes left comes back from the
+// right, one slab width further along x, and vice versa
+struct LoopArrays { double* a[4]; };
+__global__ void k_loopback_ranges(LoopArrays A, int nArr, int sLb, int sRb, int rLb, int rRb, int nToRight, int nToLeft, double w, double L)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = 0; k < nArr; k++)
+    {
+        if (t < nToRight)
+        {   // sent leftward -> arrives as "from the right"
+            double v = A.a[k][sLb + t];
+            if (k == 0) { v += w; if (v < 0) v += L; else if (v >= L) v -= L; }
+            A.a[k][rRb + t] = v;
+        }
+        if (t < nToLeft)
+        {
+            double v = A.a[k][sRb + t];
+            if (k == 0) { v -= w; if (v < 0) v += L; else if (v >= L) v -= L; }
+            A.a[k][rLb + t] = v;
+        }
+    }
+}
+
+void LoopbackExchanger::exchange_ranges(int, int, double* const* arrays, int nArr, int sLb, int sLn, int sRb, int sRn, int rLb, int rLn, int rRb, int rRn,
+                                        hipStream_t stream)
+{   // (sLn == rRn and sRn == rLn for a rank talking to itself)
+    LoopArrays A{};
+    for (int k = 0; k < nArr && k < 4; k++) A.a[k] = arrays[k];
+    const int nToRight = std::min(sLn, rRn), nToLeft = std::min(sRn, rLn), n = std::max(nToRight, nToLeft);
+    if (n > 0) hipLaunchKernelGGL(k_loopback_ranges, dim3((n + 255) / 256), dim3(256), 0, stream, A, nArr, sLb, sRb, rLb, rRb, nToRight, nToLeft, w_, L_);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -167,6 +226,22 @@ void RcclExchanger::exchange(int left, int right, const void* dSendLeft, const v
     check_nccl(a.Recv(dFromRight, bytes, ncclChar, right, c, stream), "ncclRecv(right)");
     check_nccl(a.Send(dSendRight, bytes, ncclChar, right, c, stream), "ncclSend(right)");
     check_nccl(a.Recv(dFromLeft, bytes, ncclChar, left, c, stream), "ncclRecv(left)");
+    check_nccl(a.GroupEnd(), "ncclGroupEnd");
+}
+
+void RcclExchanger::exchange_ranges(int left, int right, double* const* arrays, int nArr, int sLb, int sLn, int sRb, int sRn, int rLb, int rLn, int rRb,
+                                    int rRn, hipStream_t stream)
+{
+    RcclApi& a = rccl();
+    ncclComm_t c = (ncclComm_t)comm_;
+    check_nccl(a.GroupStart(), "ncclGroupStart");
+    for (int k = 0; k < nArr; k++)
+    {   // same pairing order as exchange(): with two ranks both neighbours are one peer and messages match in issue order
+        check_nccl(a.Send(arrays[k] + sLb, (size_t)sLn, ncclDouble, left, c, stream), "ncclSend(left)");
+        check_nccl(a.Recv(arrays[k] + rRb, (size_t)rRn, ncclDouble, right, c, stream), "ncclRecv(right)");
+        check_nccl(a.Send(arrays[k] + sRb, (size_t)sRn, ncclDouble, right, c, stream), "ncclSend(right)");
+        check_nccl(a.Recv(arrays[k] + rLb, (size_t)rLn, ncclDouble, left, c, stream), "ncclRecv(left)");
+    }
     check_nccl(a.GroupEnd(), "ncclGroupEnd");
 }
 

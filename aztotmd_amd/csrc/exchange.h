@@ -22,6 +22,11 @@ public:
     // (same size) into dFromLeft / dFromRight.  Ordered on `stream`.
     virtual void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight,
                           size_t bytes, hipStream_t stream) = 0;
+    // Lazy re-sort, plain step: both neighbours hold the same atoms in the same order as after the last full exchange, so only coordinates
+    // travel, straight between the per-atom arrays.  For each of the nArr arrays: elements [sLb, sLb + sLn) go to `left`, [sRb, sRb + sRn) to
+    // `right`; [rLb, rLb + rLn) arrive from `left`, [rRb, rRb + rRn) from `right` (the sender's counts equal the receiver's by construction)
+    virtual void exchange_ranges(int left, int right, double* const* arrays, int nArr, int sLb, int sLn, int sRb, int sRn, int rLb, int rLn, int rRb,
+                                 int rRn, hipStream_t stream) = 0;
     // element-wise sum over ranks of n doubles held on the HOST (statistics; not on the per-step path)
     virtual void allreduce_sum(double* host, int n, hipStream_t stream) = 0;
     // element-wise sum over ranks of n doubles held on the DEVICE, ordered on `stream` (Ewald structure factors: a real
@@ -38,6 +43,8 @@ public:
     CallbackExchanger(aztot_sendrecv_fn sr, aztot_allreduce_fn ar, void* ctx) : sr_(sr), ar_(ar), ctx_(ctx) {}
     void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
                   hipStream_t stream) override;
+    void exchange_ranges(int left, int right, double* const* arrays, int nArr, int sLb, int sLn, int sRb, int sRn, int rLb, int rLn, int rRb, int rRn,
+                         hipStream_t stream) override;
     void allreduce_sum(double* host, int n, hipStream_t stream) override;
     void allreduce_device(double* dev, int n, hipStream_t stream) override;
     bool device_side() const override { return false; }
@@ -59,6 +66,8 @@ public:
         : w_(slabWidth), L_(boxLength), migOff_(migOffset), haloOff_(haloOffset), migStride_(migStride), haloStride_(haloStride) {}
     void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
                   hipStream_t stream) override;
+    void exchange_ranges(int left, int right, double* const* arrays, int nArr, int sLb, int sLn, int sRb, int sRn, int rLb, int rLn, int rRb, int rRn,
+                         hipStream_t stream) override;
     void allreduce_sum(double*, int, hipStream_t) override {}
     void allreduce_device(double*, int, hipStream_t) override {}
     bool device_side() const override { return true; }
@@ -75,6 +84,8 @@ public:
     ~RcclExchanger() override;
     void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
                   hipStream_t stream) override;
+    void exchange_ranges(int left, int right, double* const* arrays, int nArr, int sLb, int sLn, int sRb, int sRn, int rLb, int rLn, int rRb, int rRn,
+                         hipStream_t stream) override;
     void allreduce_sum(double* host, int n, hipStream_t stream) override;
     void allreduce_device(double* dev, int n, hipStream_t stream) override;
     bool device_side() const override { return true; }

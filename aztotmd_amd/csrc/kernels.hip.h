@@ -674,7 +674,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_atom(StepParams P, SpecTable S,
     __shared__ double scratch[kBlock / kWave];
     const int i = cnt->ownedBegin + blockIdx.x * kBlock + threadIdx.x;
     PairAcc acc = {0, 0, 0, 0, 0, 0};
-    if (cnt->lazyViolated)
+    if (P.nranks == 1 && cnt->lazyViolated)
         for (int k = 0; k < 3; k++) { P.hw[k] += 1; P.nOff[k] = min(2 * P.hw[k] + 1, P.nc[k]); }     // an atom has left its cell's slack: reach one cell further
     if (i < cnt->ownedEnd)
     {

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
 {
     // lazy re-sort (Engine::step): an atom has left the slack of the cell it was sorted into - until the next sort the stencil reaches one cell
     // further (rare; Engine::lazy_allowed guarantees that the wider stencil still sees every cell through one image only)
-    const bool widened = P.lazySlack2 > 0.0 && counts->lazyViolated;
+    const bool widened = P.lazySlack2 > 0.0 && P.nranks == 1 && counts->lazyViolated;     // (a slab rank has no ghost layers to widen into: Engine reports the violation)
     if (widened)
     {   // nothing is known about how far the atoms have strayed beyond the slack (less than a cell, the host halves the interval at once): no pruning
         for (int k = 0; k < 3; k++) { P.hw[k] += 1; P.nOff[k] = 2 * P.hw[k] + 1; }
