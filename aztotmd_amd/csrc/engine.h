@@ -84,6 +84,9 @@ private:
     std::unique_ptr<Exchanger> ownedXch_;
 
     hipStream_t stream_ = nullptr;
+    hipStream_t commStream_ = nullptr;      // slab ranks, plain steps: the coordinate exchange runs here while the interior cells' pair forces run on stream_
+    hipEvent_t evIntegrated_ = nullptr, evHalo_ = nullptr;
+    bool overlapHalo_ = false;              // the pair launch in flight is split: interior cells now, boundary cells once evHalo_ has fired
     int capacity_ = 0;          // atoms that fit in the per-atom arrays (owned + ghosts + slack)
     int nCellAlloc_ = 0;
     int maxBlocks_ = 0;
@@ -102,7 +105,7 @@ private:
     double* dEkGlobal_ = nullptr;   // kinetic energy over all ranks (equilibration scaling only)
     char* dMsg_[4] = {nullptr, nullptr, nullptr, nullptr};   // sendLeft, sendRight, fromLeft, fromRight
     MsgLayout lay_{};
-    int pairBlocks_ = 0, pairBlocksUsed_ = 0;
+    int pairBlocks_ = 0, pairBlocksUsed_ = 0, splitBlocks_ = 0;
     // lazy re-sort (one GPU): the cells are rebuilt only every lazyK_ steps; in between the atoms keep their slots, coordinates stay unwrapped and
     // every step checks that no atom has moved farther than lazySlack_ from where it was sorted (RefPos) - see Engine::step
     bool lazyOn_ = false;

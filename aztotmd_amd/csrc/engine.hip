@@ -138,6 +138,12 @@ void Engine::construct()
     if (opt_.device < 0 || opt_.device >= ndev) throw std::runtime_error("HIP device ordinal out of range");
     HIP_CHECK(hipSetDevice(opt_.device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    if (nranks_ > 1)
+    {
+        HIP_CHECK(hipStreamCreateWithFlags(&commStream_, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&evIntegrated_, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&evHalo_, hipEventDisableTiming));
+    }
     profile_ = opt_.profile != 0;
     if (nranks_ > 1 && !xch_ && !opt_.reserved[1]) throw std::runtime_error("slab decomposition needs an exchanger");
 
@@ -242,6 +248,11 @@ void Engine::release()
     eventPool_.clear();
     for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
+    if (evIntegrated_) (void)hipEventDestroy(evIntegrated_);
+    if (evHalo_) (void)hipEventDestroy(evHalo_);
+    evIntegrated_ = evHalo_ = nullptr;
+    if (commStream_) { (void)hipStreamSynchronize(commStream_); (void)hipStreamDestroy(commStream_); }
+    commStream_ = nullptr;
     if (stream_) (void)hipStreamDestroy(stream_);
     stream_ = nullptr;
 }
@@ -289,7 +300,7 @@ void Engine::allocate()
     }
     else capacity_ = N;
     nCellAlloc_ = P_.nCellLocal;
-    pairBlocks_ = std::max(div_up(capacity_, kBlock), pair_tile_grid(P_));
+    pairBlocks_ = std::max(div_up(capacity_, kBlock), pair_tile_grid(P_) + 24);          // + 24: a split launch rounds each of its three runs up to 8 workgroups
     maxBlocks_ = std::max(div_up(capacity_, kBlock), pairBlocks_) + 1;
     auto alloc = [&](size_t bytes) { void* p = nullptr; HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16))); allocs_.push_back(p); return p; };
     const size_t nd = sizeof(double) * (size_t)capacity_, ni = sizeof(int32_t) * (size_t)capacity_;
@@ -599,7 +610,27 @@ void Engine::launch_pair()
     {
         StepParams Q = P_;
         Q.fuseKick = fuseNow_ ? 1 : 0;
-        timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_); });
+        if (overlapHalo_)
+        {   // interior x-layers [2 hw, ncx - 2 hw) first; then, once the neighbours' coordinates have landed, the two runs of boundary layers
+            const int plane = P_.nc[1] * P_.nc[2], hw = P_.hw[0];
+            PairRange in, lo, hi;
+            in.first = 2 * hw * plane; in.n = (P_.ncxLocal - 4 * hw) * plane; in.blockBase = 0;
+            lo.first = hw * plane; lo.n = hw * plane; lo.blockBase = pair_range_grid(in.n);
+            hi.first = (P_.ncxLocal - 2 * hw) * plane; hi.n = hw * plane; hi.blockBase = lo.blockBase + pair_range_grid(lo.n);
+            timed("pair_tile", [&] {
+                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, in);
+                HIP_CHECK(hipStreamWaitEvent(stream_, evHalo_, 0));
+                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, lo);
+                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, hi);
+            });
+            splitBlocks_ = hi.blockBase + pair_range_grid(hi.n);
+            overlapHalo_ = false;
+        }
+        else
+        {
+            splitBlocks_ = 0;
+            timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_); });
+        }
     }
     else
         timed("pair_atom", [&] {
@@ -607,7 +638,7 @@ void Engine::launch_pair()
                                dCellOfSorted_, dPartials_, maxBlocks_);
         });
     if (variant < 2) fuseNow_ = false;           // only the tile kernels have the fused epilogue (cannot happen: see the constructor)
-    pairBlocksUsed_ = (variant == 3) ? pair_quad_grid(P_) : (variant == 2) ? pair_tile_grid(P_) : div_up(capacity_, kBlock);
+    pairBlocksUsed_ = (variant == 3) ? pair_quad_grid(P_) : (variant == 2) ? (splitBlocks_ ? splitBlocks_ : pair_tile_grid(P_)) : div_up(capacity_, kBlock);
 }
 
 // one message to each x-neighbour: migrants + halo (packed by k_integrate1_bin; protocol in slab.hip.h)
@@ -640,10 +671,24 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
             const int left = (rank_ + nranks_ - 1) % nranks_, right = (rank_ + 1) % nranks_;
             AtomArrays& A = cur();
             double* arr[4] = {A.x, A.y, A.z, A.rad};
+            // The exchange touches the ghost ranges only, and the cells two or more layers inside the slab never read them: it runs on its
+            // own stream next to the interior cells' pair forces; the boundary cells wait for it (launch_pair).  Not while kernels are being timed
+            // one by one, not with the per-atom kernel, and not when there is no interior to speak of.
+            const int interiorLayers = P_.ncxLocal - 4 * P_.hw[0];
+            // OPT-IN (debug bit 16384): measured on one rank of 7 (loopback) the two cross-stream event waits and the two extra launches cost 30 us
+            // where the exchange they hide takes 7 (0.0685 -> 0.0981 ms/step), so the default is the serial order
+            overlapHalo_ = !profile_ && xch_->device_side() && pair_variant() == 2 && interiorLayers >= 1 && (opt_.reserved[0] & 16384);
+            if (overlapHalo_)
+            {
+                HIP_CHECK(hipEventRecord(evIntegrated_, stream_));
+                HIP_CHECK(hipStreamWaitEvent(commStream_, evIntegrated_, 0));
+            }
+            hipStream_t xs = overlapHalo_ ? commStream_ : stream_;
             timed("exchange_coords", [&] {
                 xch_->exchange_ranges(left, right, arr, P_.use_radii ? 4 : 3, halo_[0], halo_[1] - halo_[0], halo_[2], halo_[3] - halo_[2], 0, halo_[0], halo_[3],
-                                      halo_[4] - halo_[3], stream_);
+                                      halo_[4] - halo_[3], xs);
             });
+            if (overlapHalo_) HIP_CHECK(hipEventRecord(evHalo_, commStream_));
         }
         sinceSort_++;
     }

@@ -931,7 +931,10 @@ __global__ __launch_bounds__(256) void k_collect(double* __restrict__ partials, 
     double v = 0.0;
     if ((slotMask >> slot) & 1u)
     {
-        const int nb = (slot == PS_EVDW || slot == PS_ECOUL || slot == PS_DROPPED || (slot == PS_EKIN && ekinFromPair)) ? nBlocksPair : nBlocksAtoms;
+        // the accumulating slots (wall counters, dropped pairs) are read over the whole row: the pair kernels' launch layout may have changed
+        // since a drop was booked (split launches of a slab rank), and idle entries hold zeros
+        const int nb = slot_accumulates(slot) ? maxBlocks
+                       : ((slot == PS_EVDW || slot == PS_ECOUL || (slot == PS_EKIN && ekinFromPair)) ? nBlocksPair : nBlocksAtoms);
         const int per = (nb + kCollectParts - 1) / kCollectParts;
         const int b0 = part * per, b1 = min(nb, b0 + per);
         const bool clear = slot_accumulates(slot);

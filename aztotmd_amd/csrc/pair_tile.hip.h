@@ -320,7 +320,7 @@ template <int MODE, int VDW>   // 0: generic (any mix, radii) ; 1: one species, 
                       // 3: as 2 with the real-space term of the Ewald sum ; 4: one species, surk with thermostat radii (case study 2)
 __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
-                                                     double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts)
+                                                     double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase)
 {
     // lazy re-sort (Engine::step): an atom has left the slack of the cell it was sorted into - until the next sort the stencil reaches one cell
     // further (rare; Engine::lazy_allowed guarantees that the wider stencil still sees every cell through one image only)
@@ -575,48 +575,55 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
     eV = wave_sum(eV); eC = wave_sum(eC); dropped = wave_sum(dropped);
     if (lane == 0)
     {
-        put_partial(partials, maxBlocks, PS_EVDW, eV);
-        put_partial(partials, maxBlocks, PS_ECOUL, eC);
-        if (dropped != 0.0) add_partial(partials, maxBlocks, PS_DROPPED, dropped);
+        // (blockBase: a slab rank launches interior and boundary cells separately, each launch books into its own run of slots)
+        const size_t pb = (size_t)blockBase + blockIdx.x;
+        partials[(size_t)PS_EVDW * maxBlocks + pb] = eV;
+        partials[(size_t)PS_ECOUL * maxBlocks + pb] = eC;
+        if (dropped != 0.0) partials[(size_t)PS_DROPPED * maxBlocks + pb] += dropped;
     }
     if (P.fuseKick)
     {
         eK = wave_sum(eK);
-        if (lane == 0) put_partial(partials, maxBlocks, PS_EKIN, 0.5 * eK);
+        if (lane == 0) partials[(size_t)PS_EKIN * maxBlocks + blockBase + blockIdx.x] = 0.5 * eK;
     }
 }
 
+// a run of cells for one launch: first cell, number of cells, first partial-sum slot; n < 0: all the cells this rank owns
+struct PairRange { int first = 0, n = -1, blockBase = 0; };
+inline int pair_range_grid(int nCells) { return 8 * ((nCells + 7) / 8); }
+
 template <int MODE, int VDW>
 inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
-                                int maxBlocks, hipStream_t stream)
+                                int maxBlocks, hipStream_t stream, PairRange R)
 {
-    const int nRun = pair_tile_cells(P);
     const int plane = P.nc[1] * P.nc[2];
-    const int first = (P.nranks > 1) ? P.hw[0] * plane : 0;
-    hipLaunchKernelGGL((k_pair_tile<MODE, VDW>), dim3(pair_tile_grid(P)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, first, nRun, partials, maxBlocks, cnt);
+    if (R.n < 0) { R.n = pair_tile_cells(P); R.first = (P.nranks > 1) ? P.hw[0] * plane : 0; R.blockBase = 0; }
+    if (R.n == 0) return;
+    hipLaunchKernelGGL((k_pair_tile<MODE, VDW>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt,
+                       R.blockBase);
 }
 
 // P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs; 5 = a mix of them,
 // selected per species pair), <= 4 species, no radii,
 // electrostatics none / direct / Fennell / Ewald with alpha rReal <= 4 (Engine::Engine decides)
 inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
-                             double* partials, int maxBlocks, hipStream_t stream)
+                             double* partials, int maxBlocks, hipStream_t stream, PairRange R = PairRange())
 {
-    if (P.single_lj) { launch_pair_tile_as<1, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return; }
-    if (P.pad1 == 4) { launch_pair_tile_as<4, 7>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return; }     // one species, surk + radii
+    if (P.single_lj) { launch_pair_tile_as<1, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return; }
+    if (P.pad1 == 4) { launch_pair_tile_as<4, 7>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return; }     // one species, surk + radii
     if (P.pad1 == 2)
     {
         const bool ew = P.elec_type == 2;
         switch (P.vdwFamily)
         {
-        case 1: if (ew) launch_pair_tile_as<3, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return;
-        case 2: if (ew) launch_pair_tile_as<3, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return;
-        case 3: if (ew) launch_pair_tile_as<3, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return;
-        case 4: if (ew) launch_pair_tile_as<3, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return;
-        case 5: if (ew) launch_pair_tile_as<3, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); else launch_pair_tile_as<2, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream); return;
+        case 1: if (ew) launch_pair_tile_as<3, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); else launch_pair_tile_as<2, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return;
+        case 2: if (ew) launch_pair_tile_as<3, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); else launch_pair_tile_as<2, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return;
+        case 3: if (ew) launch_pair_tile_as<3, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); else launch_pair_tile_as<2, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return;
+        case 4: if (ew) launch_pair_tile_as<3, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); else launch_pair_tile_as<2, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return;
+        case 5: if (ew) launch_pair_tile_as<3, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); else launch_pair_tile_as<2, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return;
         }
     }
-    launch_pair_tile_as<0, 0>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream);
+    launch_pair_tile_as<0, 0>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R);
 }
 
 }  // namespace aztot

@@ -105,3 +105,27 @@ def test_slabs_over_rccl(nranks, name, nsteps):
     assert out["every_atom_owned_once"] and out["owned_total"] == out["n_atoms"]
     assert out["max_rel_err_vs_single"] < 1e-9, out["errs"]
     assert all(v < 1e-10 for v in out["energy_rel"].values()), out["energy_rel"]
+
+
+def test_overlapped_coordinate_exchange_changes_nothing():
+    """opt-in (debug bit 16384): plain steps of a slab rank run the coordinate exchange on a second stream beside the interior cells' pair
+    forces and launch the boundary cells afterwards (three launches instead of one).  One rank of 2 talking to itself (loopback transport: the
+    only device-side transport a one-GPU box has) with and without the overlap: per-atom state bit for bit, energies to round-off."""
+    from aztotmd_amd import api, inputs
+    import numpy as np
+    case = inputs.lj_case((42, 5, 5), a=5.735, seed=31, rc=8.5, vel_T=8.0)            # 28 cell layers along x: 14 owned layers per rank, 10 of them interior
+    res = []
+    for dbg in (0, 16384):
+        e = api.Engine(api.Model.from_case(case), slab={"rank": 1, "nranks": 2, "loopback": True}, debug=dbg)   # 14 layers = 21 lattice cells: the loopback seam matches the lattice
+        for n in (6, 30, 30):
+            e.step(n)
+        st = e.stats()
+        assert st["sort_interval"] > 1
+        s = e.state()
+        own = ~np.isnan(s["x"])
+        res.append((s, st, own))
+    assert np.array_equal(res[0][2], res[1][2]) and res[0][2].sum() > 1000
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert np.array_equal(res[0][0][k][res[0][2]], res[1][0][k][res[1][2]]), k
+    for k in ("engVdW", "engKin", "engTot"):
+        assert abs(res[0][1][k] - res[1][1][k]) <= 1e-12 * abs(res[1][1][k]), k
