@@ -116,6 +116,9 @@ private:
     int sinceSort_ = 1 << 30;       // plain steps since the last sort
     double lazySlack_ = 0.0;
     RefPos ref_{};
+    uint32_t* dCandList_ = nullptr; // per cell: the atoms its tile held when the cells were last rebuilt (pair_tile.hip.h), kTileCap entries each
+    int32_t* dCandCount_ = nullptr;
+    int candMode_ = 0;              // for the pair launch in flight: 0 none, 1 record, 2 gather
     int halo_[5] = {0, 0, 0, 0, 0};  // slab ranks: ownedBegin, end of the left boundary layers, start of the right ones, ownedEnd, nTotal (after the last sort)
     int graphCycle_ = 0;            // steps held by the captured graphs
     CellBins bins_{};               // per-cell bins of 16 atoms for pair kernel 3 (all-null when that kernel cannot run)

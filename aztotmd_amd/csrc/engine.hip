@@ -372,6 +372,12 @@ void Engine::allocate()
         if (lazyOn_)
         {
             ref_.x = (double*)alloc(nd); ref_.y = (double*)alloc(nd); ref_.z = (double*)alloc(nd);
+            if (capacity_ < (1 << 26) && !(opt_.reserved[0] & 32768))          // atom index + 6 bits of image code in 32 bits; debug 32768: no candidate lists
+            {
+                dCandList_ = (uint32_t*)alloc(sizeof(uint32_t) * (size_t)P_.nCellLocal * kTileCap);
+                dCandCount_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)P_.nCellLocal);
+                HIP_CHECK(hipMemsetAsync(dCandCount_, 0xFF, sizeof(int32_t) * (size_t)P_.nCellLocal, stream_));      // -1: no list
+            }
         }
     }
     {   // bins for pair kernel 3: only where it can run (stencil half-width 1, a specialised potential set, moderate density)
@@ -610,6 +616,8 @@ void Engine::launch_pair()
     {
         StepParams Q = P_;
         Q.fuseKick = fuseNow_ ? 1 : 0;
+        CandLists cl;
+        cl.list = dCandList_; cl.count = dCandCount_; cl.mode = candMode_;
         if (overlapHalo_)
         {   // interior x-layers [2 hw, ncx - 2 hw) first; then, once the neighbours' coordinates have landed, the two runs of boundary layers
             const int plane = P_.nc[1] * P_.nc[2], hw = P_.hw[0];
@@ -618,10 +626,10 @@ void Engine::launch_pair()
             lo.first = hw * plane; lo.n = hw * plane; lo.blockBase = pair_range_grid(in.n);
             hi.first = (P_.ncxLocal - 2 * hw) * plane; hi.n = hw * plane; hi.blockBase = lo.blockBase + pair_range_grid(lo.n);
             timed("pair_tile", [&] {
-                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, in);
+                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, in, cl);
                 HIP_CHECK(hipStreamWaitEvent(stream_, evHalo_, 0));
-                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, lo);
-                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, hi);
+                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, lo, cl);
+                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, hi, cl);
             });
             splitBlocks_ = hi.blockBase + pair_range_grid(hi.n);
             overlapHalo_ = false;
@@ -629,7 +637,7 @@ void Engine::launch_pair()
         else
         {
             splitBlocks_ = 0;
-            timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_); });
+            timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), cl); });
         }
     }
     else
@@ -691,9 +699,11 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
             if (overlapHalo_) HIP_CHECK(hipEventRecord(evHalo_, commStream_));
         }
         sinceSort_++;
+        candMode_ = 2;
     }
     else
     {
+    candMode_ = (stepMode == 1 && lazyOn_ && lazyK_ > 1) ? 1 : 0;       // a step that opens an interval of plain steps records the lists
     if (integrate_first)
         timed("integrate1_bin", [&] {
             hipLaunchKernelGGL(k_integrate1_bin<1>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,

@@ -320,7 +320,8 @@ template <int MODE, int VDW>   // 0: generic (any mix, radii) ; 1: one species, 
                       // 3: as 2 with the real-space term of the Ewald sum ; 4: one species, surk with thermostat radii (case study 2)
 __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
-                                                     double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase)
+                                                     double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase,
+                                                     uint32_t* __restrict__ candList, int32_t* __restrict__ candCount, int listMode)
 {
     // lazy re-sort (Engine::step): an atom has left the slack of the cell it was sorted into - until the next sort the stencil reaches one cell
     // further (rare; Engine::lazy_allowed guarantees that the wider stencil still sees every cell through one image only)
@@ -409,6 +410,66 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
             const float filtC = 0.0f;
             acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0; acc.eV = 0.0; acc.eC = 0.0; acc.dropped = 0.0;
             int T = 0;
+            bool flushed = false;                              // the stencil did not fit the tile in one piece
+            // Candidate list (lazy re-sort): on the step that rebuilds the cells the staging below also records WHICH atoms it kept (index + image
+            // code, in tile order); until the next rebuild the atoms keep their slots and nobody moves farther than the slack the pruning radius
+            // already allows for, so a plain step just gathers those atoms again - no run table, no pruning, no compaction (staging was 45 % of
+            // the kernel's vector instructions).  Cells whose stencil needs more than one tile, and steps after a slack violation, stage in full.
+            uint32_t* const myList = candList + (size_t)cell * kTileCap;
+            const bool record = listMode == 1 && !widened && i0 == ib;
+            const bool useList = listMode == 2 && !widened && candCount[cell] >= 0;
+            if (useList)
+            {
+                T = candCount[cell];
+                // does any neighbour cell lie across a periodic boundary (or the seam of a slab ring)?  wave-uniform
+                const int gx0 = lx + P.cx0;
+                const bool images = gx0 - P.hw[0] < 0 || gx0 + P.hw[0] >= P.nc[0] || cy - P.hw[1] < 0 || cy + P.hw[1] >= ncy || cz - P.hw[2] < 0 || cz + P.hw[2] >= ncz;
+                for (int p0 = 0; p0 < T; p0 += 4 * kWave)
+                {
+                    uint32_t ent[4];
+                    double gx[4], gy[4], gz[4], grad[4];
+                    int gtyp[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                    {
+                        const int pq = p0 + u * kWave + lane;
+                        ent[u] = (pq < T) ? myList[pq] : 0xFFFFFFFFu;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                    {
+                        gx[u] = gy[u] = gz[u] = 0.0; grad[u] = 0.0; gtyp[u] = 0;
+                        if (p0 + u * kWave + lane < T)
+                        {
+                            const int j = (int)(ent[u] & 0x3FFFFFFu);
+                            gx[u] = ld_f64(A.x, j); gy[u] = ld_f64(A.y, j); gz[u] = ld_f64(A.z, j);
+                            if (!kOneSpecies) gtyp[u] = ld_i32(A.type, j);
+                            if ((MODE == 0 && P.use_radii) || MODE == 4) grad[u] = ld_f64(A.rad, j);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                    {
+                        const int pq = p0 + u * kWave + lane;
+                        if (pq < T)
+                        {
+                            double xj = gx[u], yj = gy[u], zj = gz[u];
+                            if (images)
+                            {
+                                const int c0 = (ent[u] >> 26) & 3, c1 = (ent[u] >> 28) & 3, c2 = (ent[u] >> 30) & 3;
+                                xj += c0 == 0 ? -P.L[0] : (c0 == 2 ? P.L[0] : 0.0);
+                                yj += c1 == 0 ? -P.L[1] : (c1 == 2 ? P.L[1] : 0.0);
+                                zj += c2 == 0 ? -P.L[2] : (c2 == 2 ? P.L[2] : 0.0);
+                            }
+                            xj -= cc0; yj -= cc1; zj -= cc2;
+                            tx[pq] = xj; ty[pq] = yj; tz[pq] = zj;
+                            tw[pq] = -(float)(xj * xj + yj * yj + zj * zj);
+                            if (!kOneSpecies) ttyp[pq] = (uint8_t)gtyp[u];
+                            if (MODE == 0 || MODE == 4) trad[pq] = grad[u];
+                        }
+                    }
+                }
+            }
 
             // one LDS chunk = two passes per round of 96 candidates per lane:
             //   pass 1  distance tests only (7 fp64 ops per candidate); hits are recorded in per-lane bit masks
@@ -431,6 +492,8 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                 __builtin_amdgcn_wave_barrier();
                 T = 0;
             };
+            if (!useList)
+            {
 
             // ---- staging.  Memory latency, not bandwidth, is what staging costs (each wave would otherwise walk ~10
             // dependent s_load -> global_load round trips), so it is organised as few, wide round trips:
@@ -488,7 +551,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                     while (e < nEnt)
                     {
                         const int g = min(min(4, nEnt - e), (kTileCap - T) >> 6);
-                        if (g == 0) { process(); continue; }                   // tile full: run the passes, then go on filling
+                        if (g == 0) { process(); flushed = true; continue; }   // tile full: run the passes, then go on filling
                         const int le = min(e + (lane & 3), nEnt - 1);
                         const int vj = entJ[le], vn = entN[le], vc = entC[le];
                         double gx[4], gy[4], gz[4], grad[4];
@@ -532,6 +595,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                                     const int pp = T + lanes_below(mask);
                                     tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
                                     tw[pp] = -(float)(xj * xj + yj * yj + zj * zj);
+                                    if (record) myList[pp] = (uint32_t)(__builtin_amdgcn_readlane(vj, u) + lane) | ((uint32_t)gcode[u] << 26);
                                     if (!kOneSpecies) ttyp[pp] = (uint8_t)gtyp[u];
                                     if (MODE == 0 || MODE == 4) trad[pp] = grad[u];
                                 }
@@ -543,6 +607,8 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                     __builtin_amdgcn_wave_barrier();
                 }
             }
+            if (record && lane == 0) candCount[cell] = flushed ? -1 : T;
+            }   // full staging
             process();
 
             // fold the j-slices (fixed order) and write the force: clear_force + pair sums
@@ -590,40 +656,42 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
 
 // a run of cells for one launch: first cell, number of cells, first partial-sum slot; n < 0: all the cells this rank owns
 struct PairRange { int first = 0, n = -1, blockBase = 0; };
+// candidate lists of the lazy re-sort: mode 0 not in use, 1 record while staging (the step that rebuilt the cells), 2 gather from the lists
+struct CandLists { uint32_t* list = nullptr; int32_t* count = nullptr; int mode = 0; };
 inline int pair_range_grid(int nCells) { return 8 * ((nCells + 7) / 8); }
 
 template <int MODE, int VDW>
 inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
-                                int maxBlocks, hipStream_t stream, PairRange R)
+                                int maxBlocks, hipStream_t stream, PairRange R, CandLists C)
 {
     const int plane = P.nc[1] * P.nc[2];
     if (R.n < 0) { R.n = pair_tile_cells(P); R.first = (P.nranks > 1) ? P.hw[0] * plane : 0; R.blockBase = 0; }
     if (R.n == 0) return;
     hipLaunchKernelGGL((k_pair_tile<MODE, VDW>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt,
-                       R.blockBase);
+                       R.blockBase, C.list, C.count, C.list ? C.mode : 0);
 }
 
 // P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs; 5 = a mix of them,
 // selected per species pair), <= 4 species, no radii,
 // electrostatics none / direct / Fennell / Ewald with alpha rReal <= 4 (Engine::Engine decides)
 inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
-                             double* partials, int maxBlocks, hipStream_t stream, PairRange R = PairRange())
+                             double* partials, int maxBlocks, hipStream_t stream, PairRange R = PairRange(), CandLists C = CandLists())
 {
-    if (P.single_lj) { launch_pair_tile_as<1, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return; }
-    if (P.pad1 == 4) { launch_pair_tile_as<4, 7>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return; }     // one species, surk + radii
+    if (P.single_lj) { launch_pair_tile_as<1, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return; }
+    if (P.pad1 == 4) { launch_pair_tile_as<4, 7>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return; }     // one species, surk + radii
     if (P.pad1 == 2)
     {
         const bool ew = P.elec_type == 2;
         switch (P.vdwFamily)
         {
-        case 1: if (ew) launch_pair_tile_as<3, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); else launch_pair_tile_as<2, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return;
-        case 2: if (ew) launch_pair_tile_as<3, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); else launch_pair_tile_as<2, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return;
-        case 3: if (ew) launch_pair_tile_as<3, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); else launch_pair_tile_as<2, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return;
-        case 4: if (ew) launch_pair_tile_as<3, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); else launch_pair_tile_as<2, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return;
-        case 5: if (ew) launch_pair_tile_as<3, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); else launch_pair_tile_as<2, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R); return;
+        case 1: if (ew) launch_pair_tile_as<3, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); else launch_pair_tile_as<2, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return;
+        case 2: if (ew) launch_pair_tile_as<3, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); else launch_pair_tile_as<2, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return;
+        case 3: if (ew) launch_pair_tile_as<3, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); else launch_pair_tile_as<2, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return;
+        case 4: if (ew) launch_pair_tile_as<3, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); else launch_pair_tile_as<2, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return;
+        case 5: if (ew) launch_pair_tile_as<3, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); else launch_pair_tile_as<2, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return;
         }
     }
-    launch_pair_tile_as<0, 0>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R);
+    launch_pair_tile_as<0, 0>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C);
 }
 
 }  // namespace aztot
