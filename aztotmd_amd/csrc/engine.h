@@ -116,9 +116,15 @@ private:
     int sinceSort_ = 1 << 30;       // plain steps since the last sort
     double lazySlack_ = 0.0;
     RefPos ref_{};
-    uint32_t* dCandList_ = nullptr; // per cell: the atoms its tile held when the cells were last rebuilt (pair_tile.hip.h), kTileCap entries each
-    int32_t* dCandCount_ = nullptr;
-    int candMode_ = 0;              // for the pair launch in flight: 0 none, 1 record, 2 gather
+    // lists of the lazy re-sort (pair_tile.hip.h / pair_list.hip.h), recorded by the step that rebuilds the cells and walked by the plain steps: per cell the
+    // candidates its tile held, and per atom of the cell its partners among them, dealt evenly to the lanes
+    uint32_t* dCandList_ = nullptr;
+    int32_t* dListMeta_ = nullptr;
+    uint16_t* dPairList_ = nullptr;
+    uint8_t* dLaneCnt_ = nullptr;
+    int32_t* dNoList_ = nullptr;    // [2]: cells recorded without / with a list since the host last looked
+    bool listsOn_ = false;          // plain steps run k_pair_list (switched off when too many cells turn out to keep no list)
+    int candMode_ = 0;              // for the pair launch in flight: 0 none, 1 record, 2 plain step of the lazy re-sort
     int halo_[5] = {0, 0, 0, 0, 0};  // slab ranks: ownedBegin, end of the left boundary layers, start of the right ones, ownedEnd, nTotal (after the last sort)
     int graphCycle_ = 0;            // steps held by the captured graphs
     CellBins bins_{};               // per-cell bins of 16 atoms for pair kernel 3 (all-null when that kernel cannot run)

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <tuple>
 
@@ -12,6 +14,7 @@
 #include "ewald.hip.h"
 #include "kernels.hip.h"
 #include "pair_tile.hip.h"
+#include "pair_list.hip.h"
 #include "pair_quad.hip.h"
 #include "slab.hip.h"
 
@@ -300,7 +303,8 @@ void Engine::allocate()
     }
     else capacity_ = N;
     nCellAlloc_ = P_.nCellLocal;
-    pairBlocks_ = std::max(div_up(capacity_, kBlock), pair_tile_grid(P_) + 24);          // + 24: a split launch rounds each of its three runs up to 8 workgroups
+    // + 24: a split launch rounds each of its three runs up to 8 workgroups; the clean-up launches behind k_pair_list book into their own slots
+    pairBlocks_ = std::max(div_up(capacity_, kBlock), pair_tile_grid(P_) + 24 + 3 * pair_cleanup_grid(pair_tile_cells(P_)));
     maxBlocks_ = std::max(div_up(capacity_, kBlock), pairBlocks_) + 1;
     auto alloc = [&](size_t bytes) { void* p = nullptr; HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16))); allocs_.push_back(p); return p; };
     const size_t nd = sizeof(double) * (size_t)capacity_, ni = sizeof(int32_t) * (size_t)capacity_;
@@ -372,11 +376,17 @@ void Engine::allocate()
         if (lazyOn_)
         {
             ref_.x = (double*)alloc(nd); ref_.y = (double*)alloc(nd); ref_.z = (double*)alloc(nd);
-            if (capacity_ < (1 << 26) && !(opt_.reserved[0] & 32768))          // atom index + 6 bits of image code in 32 bits; debug 32768: no candidate lists
+            if (capacity_ < (1 << 26) && !(opt_.reserved[0] & 32768))          // atom index + 6 bits of image code in 32 bits; debug 32768: no lists
             {
-                dCandList_ = (uint32_t*)alloc(sizeof(uint32_t) * (size_t)P_.nCellLocal * kTileCap);
-                dCandCount_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)P_.nCellLocal);
-                HIP_CHECK(hipMemsetAsync(dCandCount_, 0xFF, sizeof(int32_t) * (size_t)P_.nCellLocal, stream_));      // -1: no list
+                const size_t nc = (size_t)P_.nCellLocal;
+                dCandList_ = (uint32_t*)alloc(sizeof(uint32_t) * nc * kTileCap);
+                dListMeta_ = (int32_t*)alloc(sizeof(int32_t) * nc);
+                dPairList_ = (uint16_t*)alloc(sizeof(uint16_t) * nc * kListStride16);
+                dLaneCnt_ = (uint8_t*)alloc(nc * kWave);
+                dNoList_ = (int32_t*)alloc(sizeof(int32_t) * 4);
+                HIP_CHECK(hipMemsetAsync(dListMeta_, 0xFF, sizeof(int32_t) * nc, stream_));      // -1: no list
+                HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(int32_t) * 4, stream_));
+                listsOn_ = true;
             }
         }
     }
@@ -616,28 +626,52 @@ void Engine::launch_pair()
     {
         StepParams Q = P_;
         Q.fuseKick = fuseNow_ ? 1 : 0;
-        CandLists cl;
-        cl.list = dCandList_; cl.count = dCandCount_; cl.mode = candMode_;
+        PairLists pl;
+        if (listsOn_) { pl.cand = dCandList_; pl.meta = dListMeta_; pl.pairs = dPairList_; pl.laneCnt = dLaneCnt_; pl.noList = dNoList_; }
         if (overlapHalo_)
         {   // interior x-layers [2 hw, ncx - 2 hw) first; then, once the neighbours' coordinates have landed, the two runs of boundary layers
             const int plane = P_.nc[1] * P_.nc[2], hw = P_.hw[0];
             PairRange in, lo, hi;
-            in.first = 2 * hw * plane; in.n = (P_.ncxLocal - 4 * hw) * plane; in.blockBase = 0;
-            lo.first = hw * plane; lo.n = hw * plane; lo.blockBase = pair_range_grid(in.n);
-            hi.first = (P_.ncxLocal - 2 * hw) * plane; hi.n = hw * plane; hi.blockBase = lo.blockBase + pair_range_grid(lo.n);
-            timed("pair_tile", [&] {
-                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, in, cl);
+            in.first = 2 * hw * plane; in.n = (P_.ncxLocal - 4 * hw) * plane;
+            lo.first = hw * plane; lo.n = hw * plane;
+            hi.first = (P_.ncxLocal - 2 * hw) * plane; hi.n = hw * plane;
+            const bool lists = candMode_ == 2 && pl.cand;
+            int nb = 0;
+            auto run = [&](PairRange& r) {
+                r.blockBase = nb;
+                if (lists)
+                {
+                    nb += launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, r, pl);
+                    nb += launch_pair_cleanup(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, r, pl);
+                }
+                else
+                {
+                    launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, r);
+                    nb += pair_range_grid(r.n);
+                }
+            };
+            timed(lists ? "pair_list" : "pair_tile", [&] {
+                run(in);
                 HIP_CHECK(hipStreamWaitEvent(stream_, evHalo_, 0));
-                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, lo, cl);
-                launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, hi, cl);
+                run(lo);
+                run(hi);
             });
-            splitBlocks_ = hi.blockBase + pair_range_grid(hi.n);
+            splitBlocks_ = nb;
             overlapHalo_ = false;
         }
         else
         {
             splitBlocks_ = 0;
-            timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), cl); });
+            if (candMode_ == 2 && pl.cand)       // plain step of the lazy re-sort: walk the lists; the clean-up launch stages what keeps none
+            {
+                timed("pair_list", [&] { splitBlocks_ = launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl); });
+                timed("pair_cleanup", [&] { splitBlocks_ += launch_pair_cleanup(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl); });
+            }
+            else
+            {
+                if (candMode_ == 1 && pl.cand) HIP_CHECK(hipMemsetAsync(dNoList_ + 2, 0, sizeof(int32_t), stream_));     // cells without a list: counted anew
+                timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, candMode_ == 1 ? 1 : 0); });
+            }
         }
     }
     else
@@ -952,6 +986,18 @@ void Engine::adapt_sort_interval()
     const unsigned long long zero = 0;
     HIP_CHECK(hipMemcpy(&dCounts_->maxStep2, &zero, sizeof(zero), hipMemcpyHostToDevice));
     lazyMeasured_ = true;
+    if (listsOn_)
+    {   // cells that keep no list are staged by the small clean-up launch: fine for a few, slow for many (stencils wider than one tile, cells of more than
+        // 64 atoms) - then the plain steps go back to staging every cell
+        int32_t nl[2] = {0, 0};
+        HIP_CHECK(hipMemcpy(nl, dNoList_, sizeof(nl), hipMemcpyDeviceToHost));
+        if (nl[1] > 0)
+        {
+            HIP_CHECK(hipMemset(dNoList_, 0, sizeof(nl)));          // ([2] stays: it describes the lists in force)
+            if (std::getenv("AZTOT_VERBOSE")) std::fprintf(stderr, "aztot: lists recorded since the last look: %d cells, %d of them without a list\n", nl[1], nl[0]);
+            if ((double)nl[0] > 0.02 * (double)nl[1]) { listsOn_ = false; destroy_graphs(); graphCycle_ = 0; }
+        }
+    }
     int K = lazyK_;
     if (opt_.reserved[0] & 8192)
     {   // debug: fixed interval whatever the speeds (exercises the wider-stencil fallback); violations are only counted

@@ -1,0 +1,233 @@
+// Pair-force kernel of the plain steps of the lazy re-sort: one wave64 per cell, driven by the lists the last cell rebuild recorded.
+//
+// Replaces the reference's cell_list5a + cell_list4b_noshared + pair_1 (cuPairs.cu:2266,1474,117) on the steps between two rebuilds of the
+// cell list.  The reference rebuilds everything every step (main.cu:300-326); here the step that rebuilds the cells (k_pair_tile, recording
+// launch) leaves two lists per cell:
+//   * the candidates of the cell's tile (atom index + periodic image code), and
+//   * for every atom of the cell the candidates within rc + 2 slack, dealt round-robin to the lanes that serve the atom.
+// Until the next rebuild atoms keep their slots and nobody moves farther than the slack (checked every step by k_integrate1_bin<2>; a violation
+// makes this kernel stand down and the clean-up launch of k_pair_tile stage everything with a wider stencil), so a plain step is
+//   1. gather the candidates into LDS (coordinates relative to the cell centre, as in k_pair_tile: same numbers, same arithmetic);
+//   2. every lane walks ITS list: entry -> LDS byte offset -> exact r^2 <= rc^2 test -> potential (pair_body, shared with k_pair_tile).
+// No run table, no pruning, no compaction, no distance filter, no bit masks; and because an atom's partners were dealt evenly, the lanes of a
+// wave finish together (the mask-popping loop of k_pair_tile runs max-over-lanes = 21 iterations for a mean of 14 on the 1 M-atom box; here 15-16).
+// Forces: written once per atom, no atomics, fixed summation order => bit-reproducible.  HBM traffic: the lists are streamed once per step
+// (coalesced: 4 B per candidate, 2 B per pair entry), which is what buys the 2x in vector instructions.
+#pragma once
+#include "pair_tile.hip.h"
+
+namespace aztot {
+
+template <int MODE, int VDW>
+__global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
+                                                     const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
+                                                     double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase, PairLists L)
+{
+    constexpr bool kOneSpecies = (MODE == 1 || MODE == 4);           // no species table, no type ids
+    constexpr bool kRadii = (MODE == 0 || MODE == 4);
+    __shared__ double txyz[3 * kTileLds];                            // candidate coordinates RELATIVE to the centre of the centre cell
+    __shared__ uint8_t ttyp[!kOneSpecies ? kTileLds : 1];            // species ids (< 16)
+    __shared__ double trad[kRadii ? kTileLds : 1];
+    __shared__ double pairTab[(MODE == 2 || MODE == 3) ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
+
+    const int lane = threadIdx.x;
+    const int per = (nCellsRun + 7) >> 3;
+    const int cr = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware: each XCD owns a contiguous eighth of the cells
+    double eV = 0.0, eC = 0.0, dropped = 0.0, eK = 0.0;
+    // after a slack violation (one GPU) the clean-up launch stages every cell with the wider stencil: stand down
+    const bool violated = P.nranks == 1 && counts->lazyViolated;
+    int meta = -1;
+    const int cell = firstCell + cr;
+    if (!violated && cr < nCellsRun) meta = L.meta[cell];
+    if (meta > 0)
+    {
+        const int T = meta & 0xFFF, nIter = meta >> 12;
+        const int ncy = P.nc[1], ncz = P.nc[2];
+        const int cz = cell % ncz, cy = (cell / ncz) % ncy, lx = cell / (ncy * ncz);
+        const int ib = cellStart[cell], ie = cellStart[cell + 1];
+        const double cc0 = (lx + P.cx0) * P.csz[0] + 0.5 * P.csz[0], cc1 = cy * P.csz[1] + 0.5 * P.csz[1], cc2 = cz * P.csz[2] + 0.5 * P.csz[2];
+        const DevPot lj = pots[0];
+        // this lane's first list chunk and its entry count: on their way while the candidates are gathered
+        const uint4* const pl = (const uint4*)(L.pairs + (size_t)cell * kListStride16) + lane;
+        uint4 w = {0u, 0u, 0u, 0u};
+        if (nIter > 0) w = pl[0];
+        const int cnt = L.laneCnt[(size_t)cell * kWave + lane];
+        if (MODE == 2 || MODE == 3)
+        {
+            const int np = P.nSpec * P.nSpec;
+            if (lane < np)
+            {
+                const DevPot v = pots[lane];
+                const int a = lane / P.nSpec, b = lane - a * P.nSpec;
+                double* q = pairTab + lane * kPairTabStride;
+                q[0] = v.p0; q[1] = v.p1; q[2] = v.p2; q[3] = v.p3; q[4] = v.p4;
+                q[5] = v.type ? v.r2cut : -1.0;                                   // no potential for this pair: never inside the cut-off
+                q[6] = (S.charged[a] && S.charged[b]) ? S.charge[a] * S.charge[b] * P.fcoul : 0.0;
+                if (v.type == 2) q[3] = 1.0 / v.p1;                              // buck uses p0..p2 only: 1/rho rides in the p3 slot
+                q[7] = (double)v.type;
+            }
+        }
+        // ---- the cell's own atoms: lanes are (atom slot, slice) as in k_pair_tile
+        const int nthis = ie - ib;                                     // <= 64 (cells with more keep no list)
+        const int lg = nthis <= 16 ? 4 : (nthis <= 32 ? 5 : 6);
+        const int islots = 1 << lg;
+        const int il = lane & (islots - 1), slice = lane >> lg;
+        const bool validI = il < nthis;
+        const int myi = ib + il;
+        double xi = 1e30, yi = 1e30, zi = 1e30, radi = 0.0;
+        int ti = 0;
+        if (validI)
+        {
+            xi = A.x[myi] - cc0; yi = A.y[myi] - cc1; zi = A.z[myi] - cc2;
+            if (!kOneSpecies) ti = A.type[myi];
+            if ((MODE == 0 && P.use_radii) || MODE == 4) radi = A.rad[myi];
+        }
+        // ---- gather the candidates (groups of 64; the record padded the last group with a valid atom): all list entries first, then all coordinates
+        {
+            const uint32_t* const myList = L.cand + (size_t)cell * kTileCap + lane;
+            const int rounds = (T + kWave - 1) >> 6;                   // <= 5
+            const int gx0 = lx + P.cx0;
+            // does any neighbour cell lie across a periodic boundary (or the seam of a slab ring)?  wave-uniform
+            const bool images = gx0 - P.hw[0] < 0 || gx0 + P.hw[0] >= P.nc[0] || cy - P.hw[1] < 0 || cy + P.hw[1] >= ncy || cz - P.hw[2] < 0 || cz + P.hw[2] >= ncz;
+            constexpr int kRounds = kTileCap / kWave;
+            uint32_t ent[kRounds];
+            double gx[kRounds], gy[kRounds], gz[kRounds], grad[kRounds];
+            int gtyp[kRounds];
+#pragma unroll
+            for (int u = 0; u < kRounds; u++)
+                if (u < rounds) ent[u] = myList[u * kWave];
+#pragma unroll
+            for (int u = 0; u < kRounds; u++)
+                if (u < rounds)
+                {
+                    const int j = (int)(ent[u] & 0x3FFFFFFu);
+                    gx[u] = ld_f64(A.x, j); gy[u] = ld_f64(A.y, j); gz[u] = ld_f64(A.z, j);
+                    if (!kOneSpecies) gtyp[u] = ld_i32(A.type, j);
+                    if ((MODE == 0 && P.use_radii) || MODE == 4) grad[u] = ld_f64(A.rad, j);
+                    else grad[u] = 0.0;
+                }
+#pragma unroll
+            for (int u = 0; u < kRounds; u++)
+                if (u < rounds)
+                {
+                    double xj = gx[u], yj = gy[u], zj = gz[u];
+                    if (images)
+                    {
+                        const int c0 = (ent[u] >> 26) & 3, c1 = (ent[u] >> 28) & 3, c2 = (ent[u] >> 30) & 3;
+                        xj += c0 == 0 ? -P.L[0] : (c0 == 2 ? P.L[0] : 0.0);
+                        yj += c1 == 0 ? -P.L[1] : (c1 == 2 ? P.L[1] : 0.0);
+                        zj += c2 == 0 ? -P.L[2] : (c2 == 2 ? P.L[2] : 0.0);
+                    }
+                    const int pq = u * kWave + lane;
+                    txyz[pq] = xj - cc0; txyz[kTileLds + pq] = yj - cc1; txyz[2 * kTileLds + pq] = zj - cc2;
+                    if (!kOneSpecies) ttyp[pq] = (uint8_t)gtyp[u];
+                    if (kRadii) trad[pq] = grad[u];
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- every lane walks its list
+        PairAcc acc = {0, 0, 0, 0, 0, 0};
+        int nDropHalf = 0;
+        const double ljDropR2 = P.ljDropR2;
+        const char* const tb = (const char*)txyz;
+        const int nChunks = (nIter + 7) >> 3;
+        for (int c = 0; c < nChunks; c++)
+        {
+            uint4 wn = {0u, 0u, 0u, 0u};
+            if (c + 1 < nChunks) wn = pl[(c + 1) * kWave];
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+                const int t = c * 8 + u;
+                if (t >= nIter) break;                                  // wave-uniform
+                if (t < cnt)
+                {
+                    const uint32_t ko = (u & 1) ? (ww[u >> 1] >> 16) : (ww[u >> 1] & 0xFFFFu);      // byte offset of the candidate in the tile
+                    const double dx = xi - *(const double*)(tb + ko);
+                    const double dy = yi - *(const double*)(tb + ko + kTileLds * 8);
+                    const double dz = zi - *(const double*)(tb + ko + 2 * kTileLds * 8);
+                    const double r2 = dx * dx + dy * dy + dz * dz;
+                    int tj = 0;
+                    double radj = 0.0;
+                    if (!kOneSpecies) tj = ttyp[ko >> 3];
+                    if (kRadii) radj = *(const double*)((const char*)trad + ko);
+                    pair_body<MODE, VDW>(P, S, pots, lj, pairTab, true, dx, dy, dz, r2, ti, tj, radi, radj, ljDropR2, nDropHalf, acc);
+                }
+            }
+            w = wn;
+        }
+        if (MODE != 0) acc.dropped += 0.5 * (double)nDropHalf;
+
+        // fold the j-slices (fixed order) and write the force: clear_force + pair sums
+        for (int o = kWave >> 1; o >= islots; o >>= 1)
+        {
+            acc.fx += __shfl_xor(acc.fx, o, kWave);
+            acc.fy += __shfl_xor(acc.fy, o, kWave);
+            acc.fz += __shfl_xor(acc.fz, o, kWave);
+        }
+        if (validI && slice == 0)
+        {
+            double q = 0.0;
+            if (!kOneSpecies) q = S.charge[ti];
+            const double fxi = -q * P.E[0] + acc.fx;   // clear_force integrators.cpp:17-39
+            const double fyi = -q * P.E[1] + acc.fy;
+            const double fzi = -q * P.E[2] + acc.fz;
+            A.fx[myi] = fxi; A.fy[myi] = fyi; A.fz[myi] = fzi;
+            if (P.fuseKick)
+            {   // second half-kick + kinetic energy of integrate2 (integrators.cpp:486-531 ; verlet_2stage cuMDfunc.cu:521-600)
+                const double rM = S.rMhdt[ti], m = S.mass[ti];
+                const double vx = A.vx[myi] + rM * fxi, vy = A.vy[myi] + rM * fyi, vz = A.vz[myi] + rM * fzi;
+                A.vx[myi] = vx; A.vy[myi] = vy; A.vz[myi] = vz;
+                eK += (vx * vx + vy * vy + vz * vz) * m;
+            }
+        }
+        eV = acc.eV; eC = acc.eC; dropped = acc.dropped;
+    }
+    eV = wave_sum(eV); eC = wave_sum(eC); dropped = wave_sum(dropped);
+    if (lane == 0)
+    {
+        const size_t pb = (size_t)blockBase + blockIdx.x;
+        partials[(size_t)PS_EVDW * maxBlocks + pb] = eV;
+        partials[(size_t)PS_ECOUL * maxBlocks + pb] = eC;
+        if (dropped != 0.0) partials[(size_t)PS_DROPPED * maxBlocks + pb] += dropped;
+    }
+    if (P.fuseKick)
+    {
+        eK = wave_sum(eK);
+        if (lane == 0) partials[(size_t)PS_EKIN * maxBlocks + blockBase + blockIdx.x] = 0.5 * eK;
+    }
+}
+
+template <int MODE, int VDW>
+inline void launch_pair_list_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
+                                int maxBlocks, hipStream_t stream, PairRange R, PairLists L)
+{
+    hipLaunchKernelGGL((k_pair_list<MODE, VDW>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt,
+                       R.blockBase, L);
+}
+
+// a plain step: the list kernel for every cell (launch_pair_list), then the clean-up launch of the staging kernel for the cells that keep no list
+// (launch_pair_cleanup; it books into the partial-sum slots behind the list kernel's).  Each returns the number of partial-sum slots it uses.
+inline int launch_pair_list(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
+                            double* partials, int maxBlocks, hipStream_t stream, PairRange R, PairLists L)
+{
+    pair_range_default(P, R);
+    if (R.n == 0) return 0;
+    auto list = [&]() { AZTOT_PAIR_DISPATCH(launch_pair_list_as, P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L); };
+    list();
+    return pair_range_grid(R.n);
+}
+
+inline int launch_pair_cleanup(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
+                               double* partials, int maxBlocks, hipStream_t stream, PairRange R, PairLists L)
+{
+    pair_range_default(P, R);
+    if (R.n == 0) return 0;
+    R.blockBase += pair_range_grid(R.n);
+    launch_pair_tile(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, 2);
+    return pair_cleanup_grid(R.n);
+}
+
+}  // namespace aztot

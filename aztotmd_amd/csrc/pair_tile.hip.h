@@ -75,17 +75,171 @@ constexpr int kPairTabStride = 8;   // {p0..p4, r2cut, kqq, potential type} per 
                                     // kernels sit at 10 192 B of LDS, and 10 240 B is the limit for 16 waves per CU (+64 B cost 7 %)
 constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-Jones / charge-product table in LDS
 
+// Pair lists of the lazy re-sort (pair_list.hip.h).  The step that rebuilds the cells records, next to the candidates of every cell's tile, WHICH of them
+// each atom of the cell interacts with: every candidate within rc + 2 slack - until the next rebuild no atom moves farther than the slack, so no pair inside rc
+// can be missing.  The entries of one atom are dealt round-robin to the lanes (slices) that serve it, so on the plain steps all lanes of a wave run the same
+// number of iterations (+-1) instead of max-over-lanes of a random split.  An entry is the candidate's BYTE offset in the LDS tile (index * 8 < 2^16).
+// Layout per cell: chunks of 8 iterations; chunk c holds, for lane l, the 8 entries of iterations 8c .. 8c+7 as 16 contiguous bytes at (c * 64 + l) * 16, so a
+// wave reads a chunk as one coalesced 1 KiB load.
+constexpr int kListIters = 32;                       // iterations (entries per lane) a cell's list can hold; a cell that needs more keeps no list
+constexpr int kListStride16 = kListIters * kWave;   // uint16 entries per cell
+struct ListRec
+{
+    uint16_t* pl;          // this cell's pair list, assembled in LDS (scattered 2-byte stores to global memory cost 650 us on the 1 M-atom box) and written out in one piece
+    int base;              // entries of this lane's atom recorded in earlier rounds
+    int pos;               // next entry of this lane's atom this lane writes
+    int overflow;          // some entry did not fit
+};
+
+// One pair visit of the specialised tile kernels: potential + electrostatics of the pair (i, candidate) at separation (dx, dy, dz), r2 = |d|^2.
+// `live` = the lane really has a candidate (only the unmasked Coulomb forms of tile_passes pass false).  Shared by the staging kernel below and
+// by the pair-list kernel (pair_list.hip.h), so both evaluate a pair with exactly the same operations.
+template <int MODE, int VDW>
+__device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots, const DevPot& lj, const double* pairTab,
+                                          bool live, double dx, double dy, double dz, double r2, int ti, int tj, double radi, double radj, double ljDropR2,
+                                          int& nDropHalf, PairAcc& ra)
+{
+    if (MODE == 1)
+    {   // fer_lj vdw.cpp:16-26 ; pair_inter integrators.cpp:139-185.  The atom itself (r2 == 0 exactly: its own
+        // cell is part of the tile, unshifted), candidates the conservative filter let through and dead lanes
+        // are pushed out to a huge r2, where sr6 underflows to exactly 0 and with it energy and force.
+        // The exact cut-off test and the self pair also go through the EXEC mask: the filter is conservative by 1e-5, so next to the
+        // atom's own copy (one hit in ~57) practically every lane passes and nothing diverges
+        if ((r2 > 0.0) & (r2 <= lj.r2cut))
+        {
+            const double r2i = fast_rcp(r2);
+            const double sr2 = lj.p1 * r2i;
+            const double sr6 = sr2 * sr2 * sr2;
+            ra.eV = fma(0.5 * lj.p0, sr6 * (sr6 - 1.0), ra.eV);
+            double fm = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
+            // integrators.cpp:170-174: a pair with f^2 > 1e10 is dropped.  |f| grows monotonically as r shrinks below the minimum, so
+            // the exact test is only reached (wave-uniform branch, practically never) when some lane is inside a generous radius
+            if (__builtin_expect(__any(r2 < ljDropR2), 0))
+            {
+                const bool tooBig = fm * fm > 1e10;
+                nDropHalf += tooBig ? 1 : 0;
+                fm = tooBig ? 0.0 : fm;
+            }
+            ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
+        }
+    }
+    else if (MODE == 4)
+    {   // one species, radius-dependent 'surk' potential (surk_pot cuVdW.cu:236-257; cuPairs.cu:145-146), no electrostatics: case
+        // study 2.  U = a b r^-6 (C1 a^2 b^2 / r - C2 / (ka a + kb b)) with a, b the radii the radiative thermostat writes
+        // (cuTemp.cu:757-759); same operation order as the generic kernel's vdw_force, branch-free like the Lennard-Jones body
+        const bool pairOk = live & (r2 > 0.0) & (r2 <= lj.r2cut);
+        const double r2s = pairOk ? r2 : 1e300;             // r^-6 underflows to 0: no energy, no force
+        const double ir = fast_rsqrt(r2s), r2i = ir * ir;
+        const double c2ir_sum = lj.p1 * fast_rcp(lj.p2 * radi + lj.p3 * radj);
+        const double r_prod = radi * radj;
+        const double C1ab2 = r_prod * r_prod * lj.p0;
+        const double ir6 = r2i * r2i * r2i;
+        ra.eV = fma(0.5, r_prod * ir6 * (C1ab2 * ir - c2ir_sum), ra.eV);
+        const double f = r_prod * ir6 * r2i * (7.0 * C1ab2 * ir - 6.0 * c2ir_sum);
+        const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
+        nDropHalf += tooBig ? 1 : 0;
+        const double fm = tooBig ? 0.0 : f;
+        ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
+    }
+    else if (MODE >= 2)
+    {   // one potential family for every species pair (VDW: 1 lnjs, 2 buck, 3 p746, 4 bmhs - fer_* of vdw.cpp:16-157), electrostatics
+        // none, direct, Fennell/DSF (fennel elec.cpp:430-444) or the real-space Ewald term; parameters per species pair come from a
+        // small LDS table {p0..p4, r2cut, kqq, aux}.  Branch-free: a pair outside its potential's cut-off is multiplied away.
+        const double* pp = pairTab + (ti * P.nSpec + tj) * kPairTabStride;
+        const bool pairOk = live & (r2 > 0.0) & (r2 <= P.r2Max);
+        const double r2s = pairOk ? r2 : 1e300;
+        const bool coul = (MODE == 3) || (P.elec_type != 0);               // wave-uniform
+        const bool needR = coul || VDW != 1;
+        const double ir = needR ? fast_rsqrt(r2s) : 0.0;
+        const double r2i = needR ? ir * ir : fast_rcp(r2s);
+        const double r = r2s * ir;
+        const bool vdwOk = r2s <= pp[5];
+        double f;
+        if (VDW == 1)
+        {   // fer_lj vdw.cpp:16-26: p0 = 4 eps, p1 = sigma^2, p2 = 24 eps
+            const double sr2 = vdwOk ? pp[1] * r2i : 0.0;
+            const double sr6 = sr2 * sr2 * sr2;
+            ra.eV = fma(0.5 * pp[0], sr6 * (sr6 - 1.0), ra.eV);
+            f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
+        }
+        else
+        {
+            const double w = vdwOk ? 1.0 : 0.0;
+            const double r4i = r2i * r2i, r6i = r4i * r2i;
+            const int pt = (VDW == 5) ? (int)pp[7] : VDW;                  // VDW 5: the families are mixed - per-pair type, divergent
+            double e;
+            if (pt == 1)
+            {   // fer_lj vdw.cpp:16-26
+                const double sr2 = pp[1] * r2i, sr6 = sr2 * sr2 * sr2;
+                e = pp[0] * sr6 * (sr6 - 1.0);
+                f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
+            }
+            else if (pt == 2)
+            {   // fer_buckingham vdw.cpp:60-70: A exp(-r/rho) - C/r^6 ; 1/rho in slot 3
+                const double ex = pp[0] * exp_nonpos(-r * pp[3]);
+                e = ex - pp[2] * r6i;
+                f = ex * ir * pp[3] - 6.0 * pp[2] * r4i * r4i;
+            }
+            else if (pt == 3)
+            {   // fer_746 vdw.cpp:144-157: p0/r^7 - p1/r^4 - p2/r^6
+                e = r4i * (pp[0] * r2i * ir - pp[1] - pp[2] * r2i);
+                f = r6i * (7.0 * pp[0] * r2i * ir - 4.0 * pp[1] - 6.0 * pp[2] * r2i);
+            }
+            else if (pt == 4)
+            {   // fer_bhm vdw.cpp:102-112: A exp(B (sigma - r)) - C/r^6 - D/r^8
+                const double ex = pp[0] * exp_nonpos(pp[1] * (pp[2] - r));
+                e = ex - pp[3] * r6i - pp[4] * r4i * r4i;
+                f = pp[1] * ex * ir - 6.0 * pp[3] * r4i * r4i - 8.0 * pp[4] * r4i * r4i * r2i;
+            }
+            else { e = 0.0; f = 0.0; }                                       // no potential for this species pair
+            ra.eV = fma(0.5 * w, e, ra.eV);
+            f *= w;
+        }
+        if (MODE == 2 && P.elec_type == 3)
+        {
+            const double kqq = pairOk ? pp[6] : 0.0;
+            const double ar = P.alpha * r;
+            const double ex = exp_nonpos(-ar * ar);
+            const double erfcar = erfc_given_exp(ar, ex);
+            ra.eC = fma(0.5 * kqq, erfcar * ir - P.el_scale + P.el_scale2 * (r - P.rReal), ra.eC);
+            f = fma(kqq * ir, (erfcar * r2i + P.daipi2 * ex * ir) - P.el_scale2, f);
+        }
+        else if (MODE == 3)
+        {   // real-space term of the Ewald sum: coul_iter elec.cpp:344-369 (real_ewald cuElec.cu:94-113)
+            const double kqq = pairOk ? pp[6] : 0.0;
+            const double ar = P.alpha * r;
+            const double ex = exp_nonpos(-ar * ar);
+            const double erfcar = erfc_given_exp(ar, ex);
+            ra.eC = fma(0.5 * kqq, erfcar * ir, ra.eC);
+            f = fma(kqq * ir * r2i, fma(P.daipi2 * r, ex, erfcar), f);
+        }
+        else if (MODE == 2 && P.elec_type == 1)
+        {   // direct_coul elec.cpp:415-428
+            const double kqq = pairOk ? pp[6] : 0.0;
+            ra.eC = fma(0.5 * kqq, ir, ra.eC);
+            f = fma(kqq * ir, r2i, f);
+        }
+        const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
+        nDropHalf += tooBig ? 1 : 0;
+        const double fm = tooBig ? 0.0 : f;
+        ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
+    }
+    else if (live && r2 > 0.0 && r2 <= P.r2Max)
+        pair_visit(P, S, pots, dx, dy, dz, r2, ti, tj, radi, radj, ra);
+}
+
 // STRIDE: distance (in entries) between the x, y and z arrays of the tile; NW: 32-candidate mask words per round (3 for the one-wave
 // tile of <= 320 candidates, 4 for the shared tile of k_pair_quad whose windows hold ~400)
-template <int MODE, int VDW, int LG, int STRIDE = kTileLds, int NW = 3>
+template <int MODE, int VDW, int LG, int STRIDE = kTileLds, int NW = 3, bool REC = false>
 __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots, const DevPot& lj,
                                             const double* tx, const double* ty, const double* tz, const float* tw, const uint8_t* ttyp, const double* trad,
                                             const double* pairTab, int T, int slice, double xi, double yi, double zi, int ti, double radi,
-                                            float filtB, float filtC, PairAcc& acc)
+                                            float filtB, float filtC, PairAcc& acc, ListRec* rec = nullptr)
 {
     constexpr int NS = kWave >> LG;
     const int iters = ((T + NS - 1) / NS + 3) & ~3;        // per-lane candidates, rounded up to the unroll factor
-    const double r2Filter = P.r2Max * (1.0 + 1e-13);       // conservative pass-1 threshold (see below)
+    // conservative pass-1 threshold (see below); a recording pass keeps everything within the list radius rc + 2 slack (filtB is widened by the caller)
+    const double r2Filter = (REC ? P.pruneR2 : P.r2Max) * (1.0 + 1e-13);
     const double ljDropR2 = P.ljDropR2;                   // MODE 1: no pair beyond this r^2 can break the f^2 > 1e10 rule (Engine::construct)
     int nDropHalf = 0;
     if (P.pad0 & 2048) return;                             // measurement aid (bench.py --debug 2048): staging only, forces are wrong
@@ -162,6 +316,21 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
         PairAcc& ra = acc;
         uint32_t cur = m[0], nxt = m[1], lst = m[2], ult = m[3];
         int kbase = rb * NS + slice;                       // tile index of bit 31 of `cur`
+        if (REC)
+        {   // where this lane's hits go in its atom's list: behind those of the lower slices (and of earlier rounds)
+            const int lane = threadIdx.x & (kWave - 1);
+            const int h = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
+            int below = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < NS; q++)
+            {
+                const int hq = __shfl(h, (lane & ((1 << LG) - 1)) | (q << LG), kWave);
+                below += (q < slice) ? hq : 0;
+                total += hq;
+            }
+            rec->pos = rec->base + below;
+            rec->base += total;
+        }
         if (__any((cur | nxt | lst | ult) != 0u))
         do
         {
@@ -179,136 +348,21 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
             const int b = __clz(cur | 1u);
             cur &= ~(0x80000000u >> b);                    // for a dry word this clears bit 0 of zero: harmless
             const int k = (kMaskBody || live) ? kbase + b * NS : T;       // dead lanes of the unmasked form: the first dummy
+            if (REC && live)
+            {   // entry e of the atom's list -> slice e mod NS, iteration e / NS
+                const int e = rec->pos++;
+                const int t = e >> (6 - LG);
+                const int dl = (threadIdx.x & ((1 << LG) - 1)) | ((e & (NS - 1)) << LG);
+                if (t < kListIters) rec->pl[((((t >> 3) << 6) + dl) << 3) + (t & 7)] = (uint16_t)(k << 3);
+                else rec->overflow = 1;
+            }
             const double dx = xi - tx[k], dy = yi - ty[k], dz = zi - tz[k];
             const double r2 = dx * dx + dy * dy + dz * dz;
-            if (MODE == 1)
-            {   // fer_lj vdw.cpp:16-26 ; pair_inter integrators.cpp:139-185.  The atom itself (r2 == 0 exactly: its own
-                // cell is part of the tile, unshifted), candidates the conservative filter let through and dead lanes
-                // are pushed out to a huge r2, where sr6 underflows to exactly 0 and with it energy and force.
-                // The exact cut-off test and the self pair also go through the EXEC mask: the filter is conservative by 1e-5, so next to the
-                // atom's own copy (one hit in ~57) practically every lane passes and nothing diverges
-                if ((r2 > 0.0) & (r2 <= lj.r2cut))
-                {
-                    const double r2i = fast_rcp(r2);
-                    const double sr2 = lj.p1 * r2i;
-                    const double sr6 = sr2 * sr2 * sr2;
-                    ra.eV = fma(0.5 * lj.p0, sr6 * (sr6 - 1.0), ra.eV);
-                    double fm = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
-                    // integrators.cpp:170-174: a pair with f^2 > 1e10 is dropped.  |f| grows monotonically as r shrinks below the minimum, so
-                    // the exact test is only reached (wave-uniform branch, practically never) when some lane is inside a generous radius
-                    if (__builtin_expect(__any(r2 < ljDropR2), 0))
-                    {
-                        const bool tooBig = fm * fm > 1e10;
-                        nDropHalf += tooBig ? 1 : 0;
-                        fm = tooBig ? 0.0 : fm;
-                    }
-                    ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
-                }
-            }
-            else if (MODE == 4)
-            {   // one species, radius-dependent 'surk' potential (surk_pot cuVdW.cu:236-257; cuPairs.cu:145-146), no electrostatics: case
-                // study 2.  U = a b r^-6 (C1 a^2 b^2 / r - C2 / (ka a + kb b)) with a, b the radii the radiative thermostat writes
-                // (cuTemp.cu:757-759); same operation order as the generic kernel's vdw_force, branch-free like the Lennard-Jones body
-                const bool pairOk = live & (r2 > 0.0) & (r2 <= lj.r2cut);
-                const double r2s = pairOk ? r2 : 1e300;             // r^-6 underflows to 0: no energy, no force
-                const double ir = fast_rsqrt(r2s), r2i = ir * ir;
-                const double radj = trad[k];
-                const double c2ir_sum = lj.p1 * fast_rcp(lj.p2 * radi + lj.p3 * radj);
-                const double r_prod = radi * radj;
-                const double C1ab2 = r_prod * r_prod * lj.p0;
-                const double ir6 = r2i * r2i * r2i;
-                ra.eV = fma(0.5, r_prod * ir6 * (C1ab2 * ir - c2ir_sum), ra.eV);
-                const double f = r_prod * ir6 * r2i * (7.0 * C1ab2 * ir - 6.0 * c2ir_sum);
-                const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
-                nDropHalf += tooBig ? 1 : 0;
-                const double fm = tooBig ? 0.0 : f;
-                ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
-            }
-            else if (MODE >= 2)
-            {   // one potential family for every species pair (VDW: 1 lnjs, 2 buck, 3 p746, 4 bmhs - fer_* of vdw.cpp:16-157), electrostatics
-                // none, direct, Fennell/DSF (fennel elec.cpp:430-444) or the real-space Ewald term; parameters per species pair come from a
-                // small LDS table {p0..p4, r2cut, kqq, aux}.  Branch-free: a pair outside its potential's cut-off is multiplied away.
-                const double* pp = pairTab + (ti * P.nSpec + ttyp[k]) * kPairTabStride;
-                const bool pairOk = live & (r2 > 0.0) & (r2 <= P.r2Max);
-                const double r2s = pairOk ? r2 : 1e300;
-                const bool coul = (MODE == 3) || (P.elec_type != 0);               // wave-uniform
-                const bool needR = coul || VDW != 1;
-                const double ir = needR ? fast_rsqrt(r2s) : 0.0;
-                const double r2i = needR ? ir * ir : fast_rcp(r2s);
-                const double r = r2s * ir;
-                const bool vdwOk = r2s <= pp[5];
-                double f;
-                if (VDW == 1)
-                {   // fer_lj vdw.cpp:16-26: p0 = 4 eps, p1 = sigma^2, p2 = 24 eps
-                    const double sr2 = vdwOk ? pp[1] * r2i : 0.0;
-                    const double sr6 = sr2 * sr2 * sr2;
-                    ra.eV = fma(0.5 * pp[0], sr6 * (sr6 - 1.0), ra.eV);
-                    f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
-                }
-                else
-                {
-                    const double w = vdwOk ? 1.0 : 0.0;
-                    const double r4i = r2i * r2i, r6i = r4i * r2i;
-                    const int pt = (VDW == 5) ? (int)pp[7] : VDW;                  // VDW 5: the families are mixed - per-pair type, divergent
-                    double e;
-                    if (pt == 1)
-                    {   // fer_lj vdw.cpp:16-26
-                        const double sr2 = pp[1] * r2i, sr6 = sr2 * sr2 * sr2;
-                        e = pp[0] * sr6 * (sr6 - 1.0);
-                        f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
-                    }
-                    else if (pt == 2)
-                    {   // fer_buckingham vdw.cpp:60-70: A exp(-r/rho) - C/r^6 ; 1/rho in slot 3
-                        const double ex = pp[0] * exp_nonpos(-r * pp[3]);
-                        e = ex - pp[2] * r6i;
-                        f = ex * ir * pp[3] - 6.0 * pp[2] * r4i * r4i;
-                    }
-                    else if (pt == 3)
-                    {   // fer_746 vdw.cpp:144-157: p0/r^7 - p1/r^4 - p2/r^6
-                        e = r4i * (pp[0] * r2i * ir - pp[1] - pp[2] * r2i);
-                        f = r6i * (7.0 * pp[0] * r2i * ir - 4.0 * pp[1] - 6.0 * pp[2] * r2i);
-                    }
-                    else if (pt == 4)
-                    {   // fer_bhm vdw.cpp:102-112: A exp(B (sigma - r)) - C/r^6 - D/r^8
-                        const double ex = pp[0] * exp_nonpos(pp[1] * (pp[2] - r));
-                        e = ex - pp[3] * r6i - pp[4] * r4i * r4i;
-                        f = pp[1] * ex * ir - 6.0 * pp[3] * r4i * r4i - 8.0 * pp[4] * r4i * r4i * r2i;
-                    }
-                    else { e = 0.0; f = 0.0; }                                       // no potential for this species pair
-                    ra.eV = fma(0.5 * w, e, ra.eV);
-                    f *= w;
-                }
-                if (MODE == 2 && P.elec_type == 3)
-                {
-                    const double kqq = pairOk ? pp[6] : 0.0;
-                    const double ar = P.alpha * r;
-                    const double ex = exp_nonpos(-ar * ar);
-                    const double erfcar = erfc_given_exp(ar, ex);
-                    ra.eC = fma(0.5 * kqq, erfcar * ir - P.el_scale + P.el_scale2 * (r - P.rReal), ra.eC);
-                    f = fma(kqq * ir, (erfcar * r2i + P.daipi2 * ex * ir) - P.el_scale2, f);
-                }
-                else if (MODE == 3)
-                {   // real-space term of the Ewald sum: coul_iter elec.cpp:344-369 (real_ewald cuElec.cu:94-113)
-                    const double kqq = pairOk ? pp[6] : 0.0;
-                    const double ar = P.alpha * r;
-                    const double ex = exp_nonpos(-ar * ar);
-                    const double erfcar = erfc_given_exp(ar, ex);
-                    ra.eC = fma(0.5 * kqq, erfcar * ir, ra.eC);
-                    f = fma(kqq * ir * r2i, fma(P.daipi2 * r, ex, erfcar), f);
-                }
-                else if (MODE == 2 && P.elec_type == 1)
-                {   // direct_coul elec.cpp:415-428
-                    const double kqq = pairOk ? pp[6] : 0.0;
-                    ra.eC = fma(0.5 * kqq, ir, ra.eC);
-                    f = fma(kqq * ir, r2i, f);
-                }
-                const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
-                nDropHalf += tooBig ? 1 : 0;
-                const double fm = tooBig ? 0.0 : f;
-                ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
-            }
-            else if (live && r2 > 0.0 && r2 <= P.r2Max)
-                pair_visit(P, S, pots, dx, dy, dz, r2, ti, ttyp[k], radi, trad[k], ra);
+            int tj = 0;
+            double radj = 0.0;
+            if (MODE == 0 || MODE == 2 || MODE == 3) tj = ttyp[k];
+            if (MODE == 0 || MODE == 4) radj = trad[k];
+            pair_body<MODE, VDW>(P, S, pots, lj, pairTab, live, dx, dy, dz, r2, ti, tj, radi, radj, ljDropR2, nDropHalf, ra);
             }
         } while (__any((cur | nxt | lst | ult) != 0u));
     }
@@ -316,12 +370,31 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
     if (MODE != 0) acc.dropped += 0.5 * (double)nDropHalf;     // dropped pairs, counted per lane in "half pair" units (every pair is visited from both ends)
 }
 
-template <int MODE, int VDW>   // 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;
-                      // 3: as 2 with the real-space term of the Ewald sum ; 4: one species, surk with thermostat radii (case study 2)
+// Lists of the lazy re-sort, written by the recording launch of k_pair_tile and read by k_pair_list (pair_list.hip.h)
+struct PairLists
+{
+    uint32_t* cand = nullptr;      // [nCell][kTileCap]: atom index | image code << 26 of every candidate, in tile order; padded with valid entries to a multiple of 64
+    int32_t* meta = nullptr;       // [nCell]: candidates T | list iterations << 12 ; -1: this cell keeps no list (its stencil needs more than one tile, it holds more
+                                   //          than 64 atoms, or an atom has more partners than the list holds) - such cells are staged in full on every step
+    uint16_t* pairs = nullptr;     // [nCell][kListStride16]
+    uint8_t* laneCnt = nullptr;    // [nCell][64]: entries of every lane
+    int32_t* noList = nullptr;     // [0], [1]: cells recorded without a list / cells recorded since the host last looked ; [2]: cells without a list in the lists in force
+                                   //      (zeroed by the host before every recording launch)
+};
+
+__device__ __forceinline__ int wave_max_int(int v)
+{
+#pragma unroll
+    for (int o = kWave >> 1; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+template <int MODE, int VDW, bool REC>   // MODE 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;
+                      // 3: as 2 with the real-space term of the Ewald sum ; 4: one species, surk with thermostat radii (case study 2).  REC: also record the lists
 __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase,
-                                                     uint32_t* __restrict__ candList, int32_t* __restrict__ candCount, int listMode)
+                                                     PairLists L, int onlyUnlisted)
 {
     // lazy re-sort (Engine::step): an atom has left the slack of the cell it was sorted into - until the next sort the stencil reaches one cell
     // further (rare; Engine::lazy_allowed guarantees that the wider stencil still sees every cell through one image only)
@@ -341,15 +414,52 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
     __shared__ double trad[(MODE == 0 || MODE == 4) ? kTileLds : 1];
     __shared__ double pairTab[(MODE == 2 || MODE == 3) ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
     __shared__ int32_t entJ[kWave], entN[kWave], entC[kWave];       // staging table: first atom, count (<= 64), image-shift code
+    __shared__ uint4 tlist[REC ? kListStride16 / 8 : 1];            // recording launch: the cell's pair list in its final layout
 
     const int lane = threadIdx.x;
-    // XCD-aware mapping: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous run of cells
-    const int per = (nCellsRun + 7) >> 3;
-    const int cr = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     PairAcc acc = {0, 0, 0, 0, 0, 0};
     double eV = 0.0, eC = 0.0, dropped = 0.0, eK = 0.0;
-    if (cr < nCellsRun)
+    const DevPot lj = pots[0];
+    if (MODE == 2 || MODE == 3)
     {
+        const int np = P.nSpec * P.nSpec;
+        if (lane < np)
+        {
+            const DevPot v = pots[lane];
+            const int a = lane / P.nSpec, b = lane - a * P.nSpec;
+            double* q = pairTab + lane * kPairTabStride;
+            q[0] = v.p0; q[1] = v.p1; q[2] = v.p2; q[3] = v.p3; q[4] = v.p4;
+            q[5] = v.type ? v.r2cut : -1.0;                                   // no potential for this pair: never inside the cut-off
+            q[6] = (S.charged[a] && S.charged[b]) ? S.charge[a] * S.charge[b] * P.fcoul : 0.0;
+            if (v.type == 2) q[3] = 1.0 / v.p1;                              // buck uses p0..p2 only: 1/rho rides in the p3 slot
+            q[7] = (double)v.type;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // XCD-aware mapping: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous run of cells.  A full launch has one workgroup per
+    // cell (the loop runs once); the clean-up launch behind k_pair_list (onlyUnlisted) is a small grid that strides over the cells and stages those
+    // that keep no list - or all of them after a slack violation
+    const int per = (nCellsRun + 7) >> 3;
+    const int rowStep = (int)(gridDim.x >> 3);
+    // which of this workgroup's cells need work: lane k looks at row (blockIdx >> 3) + k * rowStep of this XCD's share (the clean-up grid is sized so that
+    // 64 rows cover it).  A full launch has exactly one; the clean-up launch takes the cells without a list - or, after a slack violation, all of them
+    unsigned long long todo;
+    {
+        const int myRow = (int)(blockIdx.x >> 3) + lane * rowStep;
+        const int myCr = (blockIdx.x & 7) * per + myRow;
+        bool need = myRow < per && myCr < nCellsRun;
+        if (onlyUnlisted && !widened)
+        {
+            if (L.noList[2] == 0) need = false;                      // (wave-uniform) the last recording left no cell without a list: nothing to clean up
+            else if (need) need = L.meta[firstCell + myCr] < 0;
+        }
+        todo = __ballot(need);
+    }
+    while (todo != 0ULL)
+    {
+        const int rowK = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ULL;
+        const int cr = (blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) + rowK * rowStep;
         const int cell = firstCell + cr;
         const int ncy = P.nc[1], ncz = P.nc[2];
         const int cz = cell % ncz, cy = (cell / ncz) % ncy, lx = cell / (ncy * ncz);
@@ -368,25 +478,18 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
             const double w0 = (2 * P.hw[0] + 1) * h0, w1 = (2 * P.hw[1] + 1) * h1, w2 = (2 * P.hw[2] + 1) * h2;
             ext2 = w0 * w0 + w1 * w1 + w2 * w2;
         }
-        const double filtThr = P.r2Max + 1.9073486328125e-06 * (4.0 * ext2 + P.r2Max);      // 2^-19
-        const DevPot lj = pots[0];
-        if (MODE == 2 || MODE == 3)
-        {
-            const int np = P.nSpec * P.nSpec;
-            if (lane < np)
-            {
-                const DevPot v = pots[lane];
-                const int a = lane / P.nSpec, b = lane - a * P.nSpec;
-                double* q = pairTab + lane * kPairTabStride;
-                q[0] = v.p0; q[1] = v.p1; q[2] = v.p2; q[3] = v.p3; q[4] = v.p4;
-                q[5] = v.type ? v.r2cut : -1.0;                                   // no potential for this pair: never inside the cut-off
-                q[6] = (S.charged[a] && S.charged[b]) ? S.charge[a] * S.charge[b] * P.fcoul : 0.0;
-                if (v.type == 2) q[3] = 1.0 / v.p1;                              // buck uses p0..p2 only: 1/rho rides in the p3 slot
-                q[7] = (double)v.type;
-
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        // a recording launch keeps every candidate within the list radius rc + 2 slack (= the pruning radius) in the masks; the forces still apply the exact test
+        const double r2Keep = (REC && !widened) ? P.pruneR2 : P.r2Max;
+        const double filtThr = r2Keep + 1.9073486328125e-06 * (4.0 * ext2 + r2Keep);      // 2^-19
+        // Lists (lazy re-sort): on the step that rebuilds the cells the staging below also records WHICH atoms it kept (index + image code, in tile
+        // order) and the passes record which of them every atom of the cell interacts with; until the next rebuild the atoms keep their slots and nobody
+        // moves farther than the slack the pruning radius already allows for, so the plain steps run k_pair_list: no run table, no pruning, no
+        // compaction, no distance filter.  Cells whose stencil needs more than one tile or that hold more than 64 atoms keep no list.
+        uint32_t* const myList = REC ? L.cand + (size_t)cell * kTileCap : nullptr;
+        const bool record = REC && !widened && (ie - ib) <= kWave;
+        if (REC && !record && lane == 0) { L.meta[cell] = -1; atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
+        if (REC && blockIdx.x == 0 && lane == 0) atomicAdd(&L.noList[1], nCellsRun);          // (one atomic per launch: 74 088 of them on one address cost 650 us)
+        if (REC && record && ie == ib && lane == 0) L.meta[cell] = 0;           // an empty cell: a list with nothing in it
         for (int i0 = ib; i0 < ie; i0 += kWave)
         {
             const int nthis = min(kWave, ie - i0);
@@ -411,65 +514,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
             acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0; acc.eV = 0.0; acc.eC = 0.0; acc.dropped = 0.0;
             int T = 0;
             bool flushed = false;                              // the stencil did not fit the tile in one piece
-            // Candidate list (lazy re-sort): on the step that rebuilds the cells the staging below also records WHICH atoms it kept (index + image
-            // code, in tile order); until the next rebuild the atoms keep their slots and nobody moves farther than the slack the pruning radius
-            // already allows for, so a plain step just gathers those atoms again - no run table, no pruning, no compaction (staging was 45 % of
-            // the kernel's vector instructions).  Cells whose stencil needs more than one tile, and steps after a slack violation, stage in full.
-            uint32_t* const myList = candList + (size_t)cell * kTileCap;
-            const bool record = listMode == 1 && !widened && i0 == ib;
-            const bool useList = listMode == 2 && !widened && candCount[cell] >= 0;
-            if (useList)
-            {
-                T = candCount[cell];
-                // does any neighbour cell lie across a periodic boundary (or the seam of a slab ring)?  wave-uniform
-                const int gx0 = lx + P.cx0;
-                const bool images = gx0 - P.hw[0] < 0 || gx0 + P.hw[0] >= P.nc[0] || cy - P.hw[1] < 0 || cy + P.hw[1] >= ncy || cz - P.hw[2] < 0 || cz + P.hw[2] >= ncz;
-                for (int p0 = 0; p0 < T; p0 += 4 * kWave)
-                {
-                    uint32_t ent[4];
-                    double gx[4], gy[4], gz[4], grad[4];
-                    int gtyp[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                    {
-                        const int pq = p0 + u * kWave + lane;
-                        ent[u] = (pq < T) ? myList[pq] : 0xFFFFFFFFu;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                    {
-                        gx[u] = gy[u] = gz[u] = 0.0; grad[u] = 0.0; gtyp[u] = 0;
-                        if (p0 + u * kWave + lane < T)
-                        {
-                            const int j = (int)(ent[u] & 0x3FFFFFFu);
-                            gx[u] = ld_f64(A.x, j); gy[u] = ld_f64(A.y, j); gz[u] = ld_f64(A.z, j);
-                            if (!kOneSpecies) gtyp[u] = ld_i32(A.type, j);
-                            if ((MODE == 0 && P.use_radii) || MODE == 4) grad[u] = ld_f64(A.rad, j);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                    {
-                        const int pq = p0 + u * kWave + lane;
-                        if (pq < T)
-                        {
-                            double xj = gx[u], yj = gy[u], zj = gz[u];
-                            if (images)
-                            {
-                                const int c0 = (ent[u] >> 26) & 3, c1 = (ent[u] >> 28) & 3, c2 = (ent[u] >> 30) & 3;
-                                xj += c0 == 0 ? -P.L[0] : (c0 == 2 ? P.L[0] : 0.0);
-                                yj += c1 == 0 ? -P.L[1] : (c1 == 2 ? P.L[1] : 0.0);
-                                zj += c2 == 0 ? -P.L[2] : (c2 == 2 ? P.L[2] : 0.0);
-                            }
-                            xj -= cc0; yj -= cc1; zj -= cc2;
-                            tx[pq] = xj; ty[pq] = yj; tz[pq] = zj;
-                            tw[pq] = -(float)(xj * xj + yj * yj + zj * zj);
-                            if (!kOneSpecies) ttyp[pq] = (uint8_t)gtyp[u];
-                            if (MODE == 0 || MODE == 4) trad[pq] = grad[u];
-                        }
-                    }
-                }
-            }
+            ListRec rec;
+            rec.pl = (uint16_t*)tlist;
+            rec.base = 0; rec.pos = 0; rec.overflow = 0;
 
             // one LDS chunk = two passes per round of 96 candidates per lane:
             //   pass 1  distance tests only (7 fp64 ops per candidate); hits are recorded in per-lane bit masks
@@ -486,14 +533,21 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                     if (MODE == 0 || MODE == 4) trad[T + lane] = 1.0;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (lg == 4) tile_passes<MODE, VDW, 4>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
-                else if (lg == 5) tile_passes<MODE, VDW, 5>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
-                else tile_passes<MODE, VDW, 6>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
+                if (REC && record)
+                {
+                    if (lg == 4) tile_passes<MODE, VDW, 4, kTileLds, 3, REC>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc, &rec);
+                    else if (lg == 5) tile_passes<MODE, VDW, 5, kTileLds, 3, REC>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc, &rec);
+                    else tile_passes<MODE, VDW, 6, kTileLds, 3, REC>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc, &rec);
+                }
+                else
+                {
+                    if (lg == 4) tile_passes<MODE, VDW, 4>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
+                    else if (lg == 5) tile_passes<MODE, VDW, 5>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
+                    else tile_passes<MODE, VDW, 6>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
+                }
                 __builtin_amdgcn_wave_barrier();
                 T = 0;
             };
-            if (!useList)
-            {
 
             // ---- staging.  Memory latency, not bandwidth, is what staging costs (each wave would otherwise walk ~10
             // dependent s_load -> global_load round trips), so it is organised as few, wide round trips:
@@ -548,10 +602,12 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                     }
                     __builtin_amdgcn_wave_barrier();
                     int e = 0;
+                    bool tileFull = false;
                     while (e < nEnt)
                     {
-                        const int g = min(min(4, nEnt - e), (kTileCap - T) >> 6);
-                        if (g == 0) { process(); flushed = true; continue; }   // tile full: run the passes, then go on filling
+                        // tile full: run the passes on what is there, then go on filling (here, at the top, nothing of a group is live in registers)
+                        if (tileFull) { process(); flushed = true; tileFull = false; }
+                        const int g = min(4, nEnt - e);
                         const int le = min(e + (lane & 3), nEnt - 1);
                         const int vj = entJ[le], vn = entN[le], vc = entC[le];
                         double gx[4], gy[4], gz[4], grad[4];
@@ -570,9 +626,13 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                                 if ((MODE == 0 && P.use_radii) || MODE == 4) grad[u] = ld_f64(A.rad, j);
                             }
                         }
+                        unsigned long long kmask[4];
+                        bool keepb[4];
+                        int nKeep = 0;
 #pragma unroll
                         for (int u = 0; u < 4; u++)
                         {
+                            kmask[u] = 0ULL; keepb[u] = false;
                             if (u < g)
                             {
                                 double xj = gx[u], yj = gy[u], zj = gz[u];
@@ -584,22 +644,34 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                                     zj += c2 == 0 ? -P.L[2] : (c2 == 2 ? P.L[2] : 0.0);
                                 }
                                 xj -= cc0; yj -= cc1; zj -= cc2;
+                                gx[u] = xj; gy[u] = yj; gz[u] = zj;
                                 // distance from the centre cell's box: atoms farther than the cut-off cannot reach any atom in it
                                 const double bx = fmax(fabs(xj) - h0, 0.0);
                                 const double by = fmax(fabs(yj) - h1, 0.0);
                                 const double bz = fmax(fabs(zj) - h2, 0.0);
                                 const bool keep = (lane < gjn[u]) && (bx * bx + by * by + bz * bz) <= P.pruneR2;
-                                const unsigned long long mask = __ballot(keep);
-                                if (keep)
+                                keepb[u] = keep;
+                                kmask[u] = __ballot(keep);
+                                nKeep += __popcll(kmask[u]);
+                            }
+                        }
+                        if (T + nKeep > kTileCap) { tileFull = true; continue; }      // what this group really adds does not fit: flush, then stage the group again
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                        {
+                            if (u < g)
+                            {
+                                if (keepb[u])
                                 {
-                                    const int pp = T + lanes_below(mask);
+                                    const double xj = gx[u], yj = gy[u], zj = gz[u];
+                                    const int pp = T + lanes_below(kmask[u]);
                                     tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
                                     tw[pp] = -(float)(xj * xj + yj * yj + zj * zj);
-                                    if (record) myList[pp] = (uint32_t)(__builtin_amdgcn_readlane(vj, u) + lane) | ((uint32_t)gcode[u] << 26);
+                                    if (REC && record) myList[pp] = (uint32_t)(__builtin_amdgcn_readlane(vj, u) + lane) | ((uint32_t)gcode[u] << 26);
                                     if (!kOneSpecies) ttyp[pp] = (uint8_t)gtyp[u];
                                     if (MODE == 0 || MODE == 4) trad[pp] = grad[u];
                                 }
-                                T += __popcll(mask);
+                                T += __popcll(kmask[u]);
                             }
                         }
                         e += g;
@@ -607,9 +679,30 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            if (record && lane == 0) candCount[cell] = flushed ? -1 : T;
-            }   // full staging
+            const int Tfin = T;
             process();
+            if (REC && record)
+            {   // what the plain steps need to know about this cell
+                const int nMine = rec.base;                                     // entries of this lane's atom (idle atom slots: none)
+                const int ls = 6 - lg, ns = 1 << ls;                             // log2(slices), slices
+                const int nIter = wave_max_int((nMine + ns - 1) >> ls);
+                const bool usable = !flushed && nIter <= kListIters && !__any(rec.overflow != 0);
+                L.laneCnt[(size_t)cell * kWave + lane] = (uint8_t)max(0, (nMine - slice + ns - 1) >> ls);
+                if (usable)
+                {
+                    uint4* const out = (uint4*)(L.pairs + (size_t)cell * kListStride16);
+                    for (int c = 0; c * 8 < nIter; c++) out[c * kWave + lane] = tlist[c * kWave + lane];
+                }
+                // the plain steps gather whole groups of 64 candidates: fill the last group with a valid atom (the cell's first) - its copies land behind
+                // the candidates any list entry points at
+                const int Tpad = (Tfin + kWave - 1) & ~(kWave - 1);
+                if (usable && Tfin + lane < Tpad) myList[Tfin + lane] = (uint32_t)ib | (0x15u << 26);
+                if (lane == 0)
+                {
+                    L.meta[cell] = usable ? (Tfin | (nIter << 12)) : -1;
+                    if (!usable) { atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
+                }
+            }
 
             // fold the j-slices (fixed order) and write the force: clear_force + pair sums
             for (int o = kWave >> 1; o >= islots; o >>= 1)
@@ -641,7 +734,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
     eV = wave_sum(eV); eC = wave_sum(eC); dropped = wave_sum(dropped);
     if (lane == 0)
     {
-        // (blockBase: a slab rank launches interior and boundary cells separately, each launch books into its own run of slots)
+        // (blockBase: split launches - interior / boundary cells of a slab rank, the clean-up launch behind k_pair_list - book into their own runs of slots)
         const size_t pb = (size_t)blockBase + blockIdx.x;
         partials[(size_t)PS_EVDW * maxBlocks + pb] = eV;
         partials[(size_t)PS_ECOUL * maxBlocks + pb] = eC;
@@ -656,42 +749,56 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
 
 // a run of cells for one launch: first cell, number of cells, first partial-sum slot; n < 0: all the cells this rank owns
 struct PairRange { int first = 0, n = -1, blockBase = 0; };
-// candidate lists of the lazy re-sort: mode 0 not in use, 1 record while staging (the step that rebuilt the cells), 2 gather from the lists
-struct CandLists { uint32_t* list = nullptr; int32_t* count = nullptr; int mode = 0; };
 inline int pair_range_grid(int nCells) { return 8 * ((nCells + 7) / 8); }
-
-template <int MODE, int VDW>
-inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
-                                int maxBlocks, hipStream_t stream, PairRange R, CandLists C)
+constexpr int kCleanupGrid = 2048;             // workgroups of the clean-up launch behind k_pair_list (8 per CU); more when 64 rows per workgroup would not cover the cells
+inline int pair_cleanup_grid(int nCells) { return std::min(pair_range_grid(nCells), std::max(kCleanupGrid, 8 * ((((nCells + 7) / 8) + 63) / 64))); }
+inline void pair_range_default(const StepParams& P, PairRange& R)
 {
     const int plane = P.nc[1] * P.nc[2];
     if (R.n < 0) { R.n = pair_tile_cells(P); R.first = (P.nranks > 1) ? P.hw[0] * plane : 0; R.blockBase = 0; }
-    if (R.n == 0) return;
-    hipLaunchKernelGGL((k_pair_tile<MODE, VDW>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt,
-                       R.blockBase, C.list, C.count, C.list ? C.mode : 0);
 }
 
-// P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs; 5 = a mix of them,
-// selected per species pair), <= 4 species, no radii,
-// electrostatics none / direct / Fennell / Ewald with alpha rReal <= 4 (Engine::Engine decides)
-inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
-                             double* partials, int maxBlocks, hipStream_t stream, PairRange R = PairRange(), CandLists C = CandLists())
+// listMode 0: stage every cell ; 1: stage every cell and record the lists ; 2: clean-up launch - a small grid that stages the cells without a list
+template <int MODE, int VDW>
+inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
+                                int maxBlocks, hipStream_t stream, PairRange R, PairLists L, int listMode)
 {
-    if (P.single_lj) { launch_pair_tile_as<1, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return; }
-    if (P.pad1 == 4) { launch_pair_tile_as<4, 7>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return; }     // one species, surk + radii
-    if (P.pad1 == 2)
-    {
-        const bool ew = P.elec_type == 2;
-        switch (P.vdwFamily)
-        {
-        case 1: if (ew) launch_pair_tile_as<3, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); else launch_pair_tile_as<2, 1>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return;
-        case 2: if (ew) launch_pair_tile_as<3, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); else launch_pair_tile_as<2, 2>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return;
-        case 3: if (ew) launch_pair_tile_as<3, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); else launch_pair_tile_as<2, 3>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return;
-        case 4: if (ew) launch_pair_tile_as<3, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); else launch_pair_tile_as<2, 4>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return;
-        case 5: if (ew) launch_pair_tile_as<3, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); else launch_pair_tile_as<2, 5>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C); return;
-        }
-    }
-    launch_pair_tile_as<0, 0>(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, C);
+    pair_range_default(P, R);
+    if (R.n == 0) return;
+    if (listMode == 1)
+        hipLaunchKernelGGL((k_pair_tile<MODE, VDW, true>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt,
+                           R.blockBase, L, 0);
+    else
+        hipLaunchKernelGGL((k_pair_tile<MODE, VDW, false>), dim3(listMode == 2 ? pair_cleanup_grid(R.n) : pair_range_grid(R.n)), dim3(kWave), 0, stream,
+                           P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt, R.blockBase, L, listMode == 2 ? 1 : 0);
+}
+
+// dispatch on the potential set.  P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs; 5 = a mix of
+// them, selected per species pair), <= 4 species, no radii, electrostatics none / direct / Fennell / Ewald with alpha rReal <= 4 (Engine::Engine decides)
+#define AZTOT_PAIR_DISPATCH(LAUNCH, ...)                                                                   \
+    do {                                                                                                   \
+        if (P.single_lj) { LAUNCH<1, 1>(__VA_ARGS__); return; }                                            \
+        if (P.pad1 == 4) { LAUNCH<4, 7>(__VA_ARGS__); return; }     /* one species, surk + radii */        \
+        if (P.pad1 == 2)                                                                                   \
+        {                                                                                                  \
+            const bool ew = P.elec_type == 2;                                                              \
+            switch (P.vdwFamily)                                                                           \
+            {                                                                                              \
+            case 1: if (ew) LAUNCH<3, 1>(__VA_ARGS__); else LAUNCH<2, 1>(__VA_ARGS__); return;             \
+            case 2: if (ew) LAUNCH<3, 2>(__VA_ARGS__); else LAUNCH<2, 2>(__VA_ARGS__); return;             \
+            case 3: if (ew) LAUNCH<3, 3>(__VA_ARGS__); else LAUNCH<2, 3>(__VA_ARGS__); return;             \
+            case 4: if (ew) LAUNCH<3, 4>(__VA_ARGS__); else LAUNCH<2, 4>(__VA_ARGS__); return;             \
+            case 5: if (ew) LAUNCH<3, 5>(__VA_ARGS__); else LAUNCH<2, 5>(__VA_ARGS__); return;             \
+            }                                                                                              \
+        }                                                                                                  \
+        LAUNCH<0, 0>(__VA_ARGS__);                                                                         \
+    } while (0)
+
+inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
+                             double* partials, int maxBlocks, hipStream_t stream, PairRange R = PairRange(), PairLists L = PairLists(), int listMode = 0)
+{
+    if (!L.cand) listMode = 0;
+    AZTOT_PAIR_DISPATCH(launch_pair_tile_as, P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, listMode);
 }
 
 }  // namespace aztot
