@@ -380,11 +380,23 @@ void Engine::allocate()
             {
                 const size_t nc = (size_t)P_.nCellLocal;
                 dCandList_ = (uint32_t*)alloc(sizeof(uint32_t) * nc * kTileCap);
-                dListMeta_ = (int32_t*)alloc(sizeof(int32_t) * nc);
+                dListMeta_ = (int32_t*)alloc(sizeof(int32_t) * 2 * nc);
                 dPairList_ = (uint16_t*)alloc(sizeof(uint16_t) * nc * kListStride16);
                 dLaneCnt_ = (uint8_t*)alloc(nc * kWave);
                 dNoList_ = (int32_t*)alloc(sizeof(int32_t) * 4);
-                HIP_CHECK(hipMemsetAsync(dListMeta_, 0xFF, sizeof(int32_t) * nc, stream_));      // -1: no list
+                {   // header: -1 = no list ; second word: the cell's coordinates in the local grid (k_pair_list decodes them with shifts)
+                    if (P_.ncxLocal > 1023 || P_.nc[1] > 1023 || P_.nc[2] > 1023) throw std::runtime_error("more than 1023 cells along an axis");
+                    std::vector<int32_t> mx(2 * nc);
+                    const int ncy = P_.nc[1], ncz = P_.nc[2];
+                    for (size_t c = 0; c < nc; c++)
+                    {
+                        const int cz = (int)(c % ncz), cy = (int)((c / ncz) % ncy), lx = (int)(c / ((size_t)ncy * ncz));
+                        mx[2 * c] = -1; mx[2 * c + 1] = lx | (cy << 10) | (cz << 20);
+                    }
+                    HIP_CHECK(hipMemcpyAsync(dListMeta_, mx.data(), sizeof(int32_t) * 2 * nc, hipMemcpyHostToDevice, stream_));
+                    HIP_CHECK(hipStreamSynchronize(stream_));
+                }
+                HIP_CHECK(hipMemsetAsync(dCandList_, 0, sizeof(uint32_t) * nc * kTileCap, stream_));      // every entry is an atom index at all times
                 HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(int32_t) * 4, stream_));
                 listsOn_ = true;
             }

@@ -36,22 +36,29 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     double eV = 0.0, eC = 0.0, dropped = 0.0, eK = 0.0;
     // after a slack violation (one GPU) the clean-up launch stages every cell with the wider stencil: stand down
     const bool violated = P.nranks == 1 && counts->lazyViolated;
-    int meta = -1;
-    const int cell = firstCell + cr;
-    if (!violated && cr < nCellsRun) meta = L.meta[cell];
+    // everything that depends on the cell number only is requested at once, before anything is known about the cell (the loads stay inside the
+    // arrays whatever they return): list header, the first four groups of candidate entries, the lane's first list chunk and entry count.  A wave's
+    // life is then two memory round trips (these, then the coordinates) and the loop
+    const int cell = firstCell + min(cr, nCellsRun - 1);
+    const uint32_t* const myList = L.cand + (size_t)cell * kTileCap + lane;
+    const uint4* const pl = (const uint4*)(L.pairs + (size_t)cell * kListStride16) + lane;
+    constexpr int kRounds = kTileCap / kWave;
+    uint32_t ent[kRounds];
+#pragma unroll
+    for (int u = 0; u < kRounds - 1; u++) ent[u] = myList[u * kWave];
+    uint4 w = pl[0];
+    const int cnt = L.laneCnt[(size_t)cell * kWave + lane];
+    const int2 mx = ((const int2*)L.meta)[cell];                   // {list header, cell coordinates lx | cy << 10 | cz << 20}: one scalar load, no integer divisions
+    int meta = mx.x;
+    if (violated || cr >= nCellsRun) meta = -1;
     if (meta > 0)
     {
         const int T = meta & 0xFFF, nIter = meta >> 12;
         const int ncy = P.nc[1], ncz = P.nc[2];
-        const int cz = cell % ncz, cy = (cell / ncz) % ncy, lx = cell / (ncy * ncz);
+        const int lx = mx.y & 1023, cy = (mx.y >> 10) & 1023, cz = (mx.y >> 20) & 1023;
         const int ib = cellStart[cell], ie = cellStart[cell + 1];
         const double cc0 = (lx + P.cx0) * P.csz[0] + 0.5 * P.csz[0], cc1 = cy * P.csz[1] + 0.5 * P.csz[1], cc2 = cz * P.csz[2] + 0.5 * P.csz[2];
         const DevPot lj = pots[0];
-        // this lane's first list chunk and its entry count: on their way while the candidates are gathered
-        const uint4* const pl = (const uint4*)(L.pairs + (size_t)cell * kListStride16) + lane;
-        uint4 w = {0u, 0u, 0u, 0u};
-        if (nIter > 0) w = pl[0];
-        const int cnt = L.laneCnt[(size_t)cell * kWave + lane];
         if (MODE == 2 || MODE == 3)
         {
             const int np = P.nSpec * P.nSpec;
@@ -74,31 +81,29 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         const int il = lane & (islots - 1), slice = lane >> lg;
         const bool validI = il < nthis;
         const int myi = ib + il;
-        double xi = 1e30, yi = 1e30, zi = 1e30, radi = 0.0;
+        // (every lane loads - idle atom slots from the cell's first atom - so that the three loads travel together; a conditional load made the compiler
+        //  wait for each of them in turn)
+        const int myl = validI ? myi : ib;
+        const double xr = A.x[myl], yr = A.y[myl], zr = A.z[myl];
+        double radi = 0.0;
         int ti = 0;
-        if (validI)
-        {
-            xi = A.x[myi] - cc0; yi = A.y[myi] - cc1; zi = A.z[myi] - cc2;
-            if (!kOneSpecies) ti = A.type[myi];
-            if ((MODE == 0 && P.use_radii) || MODE == 4) radi = A.rad[myi];
-        }
+        if (!kOneSpecies) ti = A.type[myl];
+        if ((MODE == 0 && P.use_radii) || MODE == 4) radi = A.rad[myl];
         // ---- gather the candidates (groups of 64; the record padded the last group with a valid atom): all list entries first, then all coordinates
         {
-            const uint32_t* const myList = L.cand + (size_t)cell * kTileCap + lane;
             const int rounds = (T + kWave - 1) >> 6;                   // <= 5
             const int gx0 = lx + P.cx0;
             // does any neighbour cell lie across a periodic boundary (or the seam of a slab ring)?  wave-uniform
             const bool images = gx0 - P.hw[0] < 0 || gx0 + P.hw[0] >= P.nc[0] || cy - P.hw[1] < 0 || cy + P.hw[1] >= ncy || cz - P.hw[2] < 0 || cz + P.hw[2] >= ncz;
-            constexpr int kRounds = kTileCap / kWave;
-            uint32_t ent[kRounds];
             double gx[kRounds], gy[kRounds], gz[kRounds], grad[kRounds];
             int gtyp[kRounds];
+            ent[kRounds - 1] = 0u;
+            if (rounds == kRounds) ent[kRounds - 1] = myList[(kRounds - 1) * kWave];
+            // the first four groups are gathered whatever T is (stale entries are atom indices too: the array starts out zeroed and only indices are ever
+            // written); only the fifth is conditional
 #pragma unroll
             for (int u = 0; u < kRounds; u++)
-                if (u < rounds) ent[u] = myList[u * kWave];
-#pragma unroll
-            for (int u = 0; u < kRounds; u++)
-                if (u < rounds)
+                if (u < kRounds - 1 || rounds == kRounds)
                 {
                     const int j = (int)(ent[u] & 0x3FFFFFFu);
                     gx[u] = ld_f64(A.x, j); gy[u] = ld_f64(A.y, j); gz[u] = ld_f64(A.z, j);
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
                 }
 #pragma unroll
             for (int u = 0; u < kRounds; u++)
-                if (u < rounds)
+                if (u < kRounds - 1 || rounds == kRounds)
                 {
                     double xj = gx[u], yj = gy[u], zj = gz[u];
                     if (images)
@@ -124,6 +129,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
                     if (kRadii) trad[pq] = grad[u];
                 }
         }
+        const double xi = validI ? xr - cc0 : 1e30, yi = validI ? yr - cc1 : 1e30, zi = validI ? zr - cc2 : 1e30;
         __builtin_amdgcn_wave_barrier();
 
         // ---- every lane walks its list
@@ -132,29 +138,39 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         const double ljDropR2 = P.ljDropR2;
         const char* const tb = (const char*)txyz;
         const int nChunks = (nIter + 7) >> 3;
+        // software-pipelined: the candidate of iteration t + 1 is read from LDS before the potential of iteration t is evaluated (entries behind a lane's
+        // last one are zero - the record clears the list buffer - so the read ahead is always a valid one)
+        double xj, yj, zj, radj = 0.0;
+        int tj = 0;
+        auto fetch = [&](uint32_t ko, double& x, double& y, double& z, int& ty, double& rd) {
+            x = *(const double*)(tb + ko);
+            y = *(const double*)(tb + ko + kTileLds * 8);
+            z = *(const double*)(tb + ko + 2 * kTileLds * 8);
+            if (!kOneSpecies) ty = ttyp[ko >> 3];
+            if (kRadii) rd = *(const double*)((const char*)trad + ko);
+        };
+        fetch(nIter > 0 ? (w.x & 0xFFFFu) : 0u, xj, yj, zj, tj, radj);
         for (int c = 0; c < nChunks; c++)
         {
             uint4 wn = {0u, 0u, 0u, 0u};
             if (c + 1 < nChunks) wn = pl[(c + 1) * kWave];
-            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+            const uint32_t ww[5] = {w.x, w.y, w.z, w.w, wn.x};
 #pragma unroll
             for (int u = 0; u < 8; u++)
             {
                 const int t = c * 8 + u;
                 if (t >= nIter) break;                                  // wave-uniform
+                const uint32_t kn = ((u + 1) & 1) ? (ww[(u + 1) >> 1] >> 16) : (ww[(u + 1) >> 1] & 0xFFFFu);      // byte offset of the next candidate in the tile
+                double xn, yn, zn, radn = 0.0;
+                int tn = 0;
+                fetch(kn, xn, yn, zn, tn, radn);
                 if (t < cnt)
                 {
-                    const uint32_t ko = (u & 1) ? (ww[u >> 1] >> 16) : (ww[u >> 1] & 0xFFFFu);      // byte offset of the candidate in the tile
-                    const double dx = xi - *(const double*)(tb + ko);
-                    const double dy = yi - *(const double*)(tb + ko + kTileLds * 8);
-                    const double dz = zi - *(const double*)(tb + ko + 2 * kTileLds * 8);
+                    const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
                     const double r2 = dx * dx + dy * dy + dz * dz;
-                    int tj = 0;
-                    double radj = 0.0;
-                    if (!kOneSpecies) tj = ttyp[ko >> 3];
-                    if (kRadii) radj = *(const double*)((const char*)trad + ko);
                     pair_body<MODE, VDW>(P, S, pots, lj, pairTab, true, dx, dy, dz, r2, ti, tj, radi, radj, ljDropR2, nDropHalf, acc);
                 }
+                xj = xn; yj = yn; zj = zn; tj = tn; radj = radn;
             }
             w = wn;
         }

@@ -374,7 +374,8 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
 struct PairLists
 {
     uint32_t* cand = nullptr;      // [nCell][kTileCap]: atom index | image code << 26 of every candidate, in tile order; padded with valid entries to a multiple of 64
-    int32_t* meta = nullptr;       // [nCell]: candidates T | list iterations << 12 ; -1: this cell keeps no list (its stencil needs more than one tile, it holds more
+    int32_t* meta = nullptr;       // [nCell][2]: {candidates T | list iterations << 12, cell coordinates lx | cy << 10 | cz << 20 (written once by the host)} ;
+                                   //          first word -1: this cell keeps no list (its stencil needs more than one tile, it holds more
                                    //          than 64 atoms, or an atom has more partners than the list holds) - such cells are staged in full on every step
     uint16_t* pairs = nullptr;     // [nCell][kListStride16]
     uint8_t* laneCnt = nullptr;    // [nCell][64]: entries of every lane
@@ -441,25 +442,25 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
     // that keep no list - or all of them after a slack violation
     const int per = (nCellsRun + 7) >> 3;
     const int rowStep = (int)(gridDim.x >> 3);
-    // which of this workgroup's cells need work: lane k looks at row (blockIdx >> 3) + k * rowStep of this XCD's share (the clean-up grid is sized so that
-    // 64 rows cover it).  A full launch has exactly one; the clean-up launch takes the cells without a list - or, after a slack violation, all of them
+    // which of this workgroup's cells need work: lane k of batch b looks at row (blockIdx >> 3) + (64 b + k) * rowStep of this XCD's share.  A full launch
+    // has exactly one cell; the clean-up launch (a few workgroups that stride over all cells) takes those without a list - or, after a slack violation, all
+    bool cleanupIdle = false;
+    if (onlyUnlisted && !widened) cleanupIdle = L.noList[2] == 0;       // the last recording left no cell without a list: nothing to clean up
+    for (int rowBase = (int)(blockIdx.x >> 3); rowBase < per && !cleanupIdle; rowBase += kWave * rowStep)
+    {
     unsigned long long todo;
     {
-        const int myRow = (int)(blockIdx.x >> 3) + lane * rowStep;
+        const int myRow = rowBase + lane * rowStep;
         const int myCr = (blockIdx.x & 7) * per + myRow;
         bool need = myRow < per && myCr < nCellsRun;
-        if (onlyUnlisted && !widened)
-        {
-            if (L.noList[2] == 0) need = false;                      // (wave-uniform) the last recording left no cell without a list: nothing to clean up
-            else if (need) need = L.meta[firstCell + myCr] < 0;
-        }
+        if (onlyUnlisted && !widened && need) need = L.meta[2 * (firstCell + myCr)] < 0;
         todo = __ballot(need);
     }
     while (todo != 0ULL)
     {
         const int rowK = __ffsll((long long)todo) - 1;
         todo &= todo - 1ULL;
-        const int cr = (blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) + rowK * rowStep;
+        const int cr = (blockIdx.x & 7) * per + rowBase + rowK * rowStep;
         const int cell = firstCell + cr;
         const int ncy = P.nc[1], ncz = P.nc[2];
         const int cz = cell % ncz, cy = (cell / ncz) % ncy, lx = cell / (ncy * ncz);
@@ -487,9 +488,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
         // compaction, no distance filter.  Cells whose stencil needs more than one tile or that hold more than 64 atoms keep no list.
         uint32_t* const myList = REC ? L.cand + (size_t)cell * kTileCap : nullptr;
         const bool record = REC && !widened && (ie - ib) <= kWave;
-        if (REC && !record && lane == 0) { L.meta[cell] = -1; atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
+        if (REC && !record && lane == 0) { L.meta[2 * cell] = -1; atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
         if (REC && blockIdx.x == 0 && lane == 0) atomicAdd(&L.noList[1], nCellsRun);          // (one atomic per launch: 74 088 of them on one address cost 650 us)
-        if (REC && record && ie == ib && lane == 0) L.meta[cell] = 0;           // an empty cell: a list with nothing in it
+        if (REC && record && ie == ib && lane == 0) L.meta[2 * cell] = 0;           // an empty cell: a list with nothing in it
         for (int i0 = ib; i0 < ie; i0 += kWave)
         {
             const int nthis = min(kWave, ie - i0);
@@ -516,6 +517,11 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
             bool flushed = false;                              // the stencil did not fit the tile in one piece
             ListRec rec;
             rec.pl = (uint16_t*)tlist;
+            if (REC && record)
+            {   // entries nobody writes read as offset 0: k_pair_list reads one candidate ahead of the one it evaluates
+                const uint4 zero4 = {0u, 0u, 0u, 0u};
+                for (int q = lane; q < kListStride16 / 8; q += kWave) tlist[q] = zero4;
+            }
             rec.base = 0; rec.pos = 0; rec.overflow = 0;
 
             // one LDS chunk = two passes per round of 96 candidates per lane:
@@ -699,7 +705,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                 if (usable && Tfin + lane < Tpad) myList[Tfin + lane] = (uint32_t)ib | (0x15u << 26);
                 if (lane == 0)
                 {
-                    L.meta[cell] = usable ? (Tfin | (nIter << 12)) : -1;
+                    L.meta[2 * cell] = usable ? (Tfin | (nIter << 12)) : -1;
                     if (!usable) { atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
                 }
             }
@@ -731,6 +737,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
             eV += acc.eV; eC += acc.eC; dropped += acc.dropped;
         }
     }
+    }   // batches of rows
     eV = wave_sum(eV); eC = wave_sum(eC); dropped = wave_sum(dropped);
     if (lane == 0)
     {
@@ -750,8 +757,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
 // a run of cells for one launch: first cell, number of cells, first partial-sum slot; n < 0: all the cells this rank owns
 struct PairRange { int first = 0, n = -1, blockBase = 0; };
 inline int pair_range_grid(int nCells) { return 8 * ((nCells + 7) / 8); }
-constexpr int kCleanupGrid = 2048;             // workgroups of the clean-up launch behind k_pair_list (8 per CU); more when 64 rows per workgroup would not cover the cells
-inline int pair_cleanup_grid(int nCells) { return std::min(pair_range_grid(nCells), std::max(kCleanupGrid, 8 * ((((nCells + 7) / 8) + 63) / 64))); }
+constexpr int kCleanupGrid = 256;              // workgroups of the clean-up launch behind k_pair_list: one per CU (it has work to do only for cells without a list
+                                               // and on the rare steps after a slack violation; then it is slow, and exact)
+inline int pair_cleanup_grid(int nCells) { return std::min(pair_range_grid(nCells), kCleanupGrid); }
 inline void pair_range_default(const StepParams& P, PairRange& R)
 {
     const int plane = P.nc[1] * P.nc[2];
