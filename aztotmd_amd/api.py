@@ -11,7 +11,7 @@ _LIB = None
 
 STAT_FIELDS = ("step", "time", "engTot", "engKin", "engVdW", "engCoul", "engElecField", "engTemp", "engPot", "temperature",
                "posMom", "negMom", "posCross", "negCross", "pressure", "pairs_dropped", "n_cells", "nose_chit", "nose_conint",
-               "engBond", "engAngle", "engCoulRec", "engCoulConst", "sort_interval", "sort_violations")
+               "engBond", "engAngle", "engCoulRec", "engCoulConst", "sort_interval", "sort_violations", "pair_lists", "cells_without_list")
 
 
 class AztotError(RuntimeError):
@@ -74,7 +74,8 @@ class _Stats(C.Structure):
                 ("temperature", C.c_double), ("posMom", C.c_double * 3), ("negMom", C.c_double * 3), ("posCross", C.c_int64 * 3),
                 ("negCross", C.c_int64 * 3), ("pressure", C.c_double), ("pairs_dropped", C.c_int64), ("n_cells", C.c_int64),
                 ("nose_chit", C.c_double), ("nose_conint", C.c_double), ("engBond", C.c_double), ("engAngle", C.c_double),
-                ("engCoulRec", C.c_double), ("engCoulConst", C.c_double), ("sort_interval", C.c_int64), ("sort_violations", C.c_int64)]
+                ("engCoulRec", C.c_double), ("engCoulConst", C.c_double), ("sort_interval", C.c_int64), ("sort_violations", C.c_int64),
+                ("pair_lists", C.c_int64), ("cells_without_list", C.c_int64)]
 
 
 class _State(C.Structure):

@@ -683,6 +683,7 @@ void Engine::launch_pair()
             {
                 if (candMode_ == 1 && pl.cand) HIP_CHECK(hipMemsetAsync(dNoList_ + 2, 0, sizeof(int32_t), stream_));     // cells without a list: counted anew
                 timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, candMode_ == 1 ? 1 : 0); });
+                if (candMode_ == 1 && pl.cand) timed("build_lists", [&] { launch_build_lists(Q, cur(), dCellStart_, stream_, PairRange(), pl); });
             }
         }
     }
@@ -1007,7 +1008,7 @@ void Engine::adapt_sort_interval()
         {
             HIP_CHECK(hipMemset(dNoList_, 0, sizeof(nl)));          // ([2] stays: it describes the lists in force)
             if (std::getenv("AZTOT_VERBOSE")) std::fprintf(stderr, "aztot: lists recorded since the last look: %d cells, %d of them without a list\n", nl[1], nl[0]);
-            if ((double)nl[0] > 0.02 * (double)nl[1]) { listsOn_ = false; destroy_graphs(); graphCycle_ = 0; }
+            if ((double)nl[0] > 0.02 * (double)nl[1] && !(opt_.reserved[0] & 65536)) { listsOn_ = false; destroy_graphs(); graphCycle_ = 0; }
         }
     }
     int K = lazyK_;
@@ -1082,6 +1083,14 @@ void Engine::get_stats(aztot_stats& out)
     out.n_cells = (int64_t)P_.nc[0] * P_.nc[1] * P_.nc[2];
     out.nose_chit = s.chit; out.nose_conint = s.conint;
     out.sort_interval = lazyOn_ ? lazyK_ : 1; out.sort_violations = lazyViolations_;
+    out.pair_lists = (listsOn_ && lazyOn_ && lazyK_ > 1) ? 1 : 0;
+    out.cells_without_list = 0;
+    if (listsOn_)
+    {
+        int32_t nl = 0;
+        HIP_CHECK(hipMemcpy(&nl, dNoList_ + 2, sizeof(nl), hipMemcpyDeviceToHost));
+        out.cells_without_list = nl;
+    }
     // pressure from the wall momentum over the window since the previous evaluation (main.cpp:143-163)
     if (s.step - lastPresStep_ >= std::max(1, model_.stat))
     {

@@ -83,13 +83,6 @@ constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-
 // wave reads a chunk as one coalesced 1 KiB load.
 constexpr int kListIters = 32;                       // iterations (entries per lane) a cell's list can hold; a cell that needs more keeps no list
 constexpr int kListStride16 = kListIters * kWave;   // uint16 entries per cell
-struct ListRec
-{
-    uint16_t* pl;          // this cell's pair list, assembled in LDS (scattered 2-byte stores to global memory cost 650 us on the 1 M-atom box) and written out in one piece
-    int base;              // entries of this lane's atom recorded in earlier rounds
-    int pos;               // next entry of this lane's atom this lane writes
-    int overflow;          // some entry did not fit
-};
 
 // One pair visit of the specialised tile kernels: potential + electrostatics of the pair (i, candidate) at separation (dx, dy, dz), r2 = |d|^2.
 // `live` = the lane really has a candidate (only the unmasked Coulomb forms of tile_passes pass false).  Shared by the staging kernel below and
@@ -228,85 +221,95 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
         pair_visit(P, S, pots, dx, dy, dz, r2, ti, tj, radi, radj, ra);
 }
 
-// STRIDE: distance (in entries) between the x, y and z arrays of the tile; NW: 32-candidate mask words per round (3 for the one-wave
-// tile of <= 320 candidates, 4 for the shared tile of k_pair_quad whose windows hold ~400)
-template <int MODE, int VDW, int LG, int STRIDE = kTileLds, int NW = 3, bool REC = false>
+// Pass 1 of one round (NW words of 32 candidates per lane, starting at per-lane candidate rb): distance tests only; the hits come back as per-lane bit
+// masks m[0..NW-1], candidate number b of a word at bit 31 - b.  LG = log2(atom slots), NS = 64 >> LG lanes (slices) per atom; STRIDE: distance (in
+// entries) between the x, y and z arrays of the tile.  Shared by the force kernels (threshold rc^2) and by k_build_lists (threshold (rc + 2 slack)^2).
+template <int LG, int STRIDE, int NW>
+__device__ __forceinline__ void tile_filter(const double* tx, const double* ty, const double* tz, const float* tw, int rb, int iters, int slice,
+                                            double xi, double yi, double zi, float filtB, double r2Filter, uint32_t (&m)[4])
+{
+    constexpr int NS = kWave >> LG;
+#pragma unroll
+    for (int w = 0; w < NW; w++)
+    {
+        const int tb = rb + w * 32;
+        const int nb = min(32, iters - tb);            // multiple of 4, may be <= 0
+        uint32_t miss = 0xFFFFFFFFu;                   // one bit per candidate, 1 = outside the cut-off
+        if (LG == 4)
+        {   // 16 atoms x 4 slices: the distance filter of a block of 16 candidates x 16 atoms is ONE v_mfma_f32_16x16x4_f32:
+            //   D[cand][atom] = -|rj|^2 + (xj, yj, zj, 1) . (2 xi, 2 yi, 2 zi, thr - |ri|^2) = thr - |ri - rj|^2
+            // in f32 on cell-relative coordinates (|x| < cell/2 + rc), thr widened by the f32 error bound, so the filter stays
+            // conservative; pass 2 applies the exact fp64 test.  The matrix instruction holds the vector pipe for ~38 cycles per 256
+            // tests where the fp64 VALU form below needs ~140 (tools/ubench/valu_rates.hip); an fp64 MFMA would not help: it runs on
+            // the same fp64 units as v_fma_f64 (measured: additive).  Operand maps (gfx950): A[row l&15][k l>>4], B[k l>>4][col l&15],
+            // C/D[row 4 (l>>4) + reg][col l&15].  Rows are fed in the order perm(c) = (c >> 2) + 4 (c & 3), which makes register r of the
+            // lane (atom l&15, slice l>>4) the candidate 16 B + slice + 4 r: exactly the lane's own interleaved candidates; the
+            // -|rj|^2 of those four candidates arrive as the C operand.
+            const int lane = threadIdx.x & (kWave - 1);
+            const int c = lane & 15, k = lane >> 4;
+            const int permc = (c >> 2) + ((c & 3) << 2);
+            // lanes k = 3 feed the constant 1; they read (and ignore) the y array: banks 32-63, away from the z lanes of their half-wave
+            const double* pa = tx + (k == 3 ? 1 : k) * STRIDE + tb * NS + permc;
+            const float* pc = tw + tb * NS + k;        // -|rj|^2 of the lane's candidates k, k + 4, k + 8, k + 12 of every block
+            const int nblk = nb >> 2;                  // blocks of 16 candidates in this word (<= 8)
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+            {
+                if (q < nblk)
+                {
+                    const float av = (float)pa[q * 16];
+                    const float a = (k == 3) ? 1.0f : av;
+                    const float4_t cw = {pc[q * 16], pc[q * 16 + 4], pc[q * 16 + 8], pc[q * 16 + 12]};      // two ds_read2_b32
+                    const float4_t d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, filtB, cw, 0, 0, 0);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[0]), 31);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[1]), 31);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[2]), 31);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[3]), 31);   // newest candidate in bit 0
+                }
+            }
+            m[w] = (nb > 0) ? (~miss << (32 - nb)) : 0u;
+            continue;
+        }
+        const double* px = &tx[tb * NS + slice];
+        const double* py = &ty[tb * NS + slice];
+        const double* pz = &tz[tb * NS + slice];
+        for (int b = 0; b < nb; b += 4)
+        {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                // 7 VALU per candidate: 3 subtractions, 3 FMAs that leave d = rc^2(1+eps) - r^2, and one v_alignbit
+                // that shifts the sign of d into the mask.  The filter is conservative by eps; pass 2 applies the
+                // exact r^2 <= rc^2 test of the reference (pair_inter integrators.cpp:148).
+                const double dx = xi - px[u * NS], dy = yi - py[u * NS], dz = zi - pz[u * NS];
+                const double d = fma(-dz, dz, fma(-dy, dy, fma(-dx, dx, r2Filter)));
+                miss = __builtin_amdgcn_alignbit(miss, (uint32_t)(__double_as_longlong(d) >> 32), 31);   // newest candidate in bit 0
+            }
+            px += 4 * NS; py += 4 * NS; pz += 4 * NS;
+        }
+        // left-align: candidate number b of this word sits at bit 31 - b, whatever the word length
+        m[w] = (nb > 0) ? (~miss << (32 - nb)) : 0u;
+    }
+}
+
+// The two passes over one staged chunk.  NW: 32-candidate mask words per round (3 for the one-wave tile of <= 320 candidates, 4 for the shared tile of
+// k_pair_quad whose windows hold ~400)
+template <int MODE, int VDW, int LG, int STRIDE = kTileLds, int NW = 3>
 __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots, const DevPot& lj,
                                             const double* tx, const double* ty, const double* tz, const float* tw, const uint8_t* ttyp, const double* trad,
                                             const double* pairTab, int T, int slice, double xi, double yi, double zi, int ti, double radi,
-                                            float filtB, float filtC, PairAcc& acc, ListRec* rec = nullptr)
+                                            float filtB, float filtC, PairAcc& acc)
 {
     constexpr int NS = kWave >> LG;
     const int iters = ((T + NS - 1) / NS + 3) & ~3;        // per-lane candidates, rounded up to the unroll factor
-    // conservative pass-1 threshold (see below); a recording pass keeps everything within the list radius rc + 2 slack (filtB is widened by the caller)
-    const double r2Filter = (REC ? P.pruneR2 : P.r2Max) * (1.0 + 1e-13);
+    const double r2Filter = P.r2Max * (1.0 + 1e-13);       // conservative pass-1 threshold
     const double ljDropR2 = P.ljDropR2;                   // MODE 1: no pair beyond this r^2 can break the f^2 > 1e10 rule (Engine::construct)
     int nDropHalf = 0;
     if (P.pad0 & 2048) return;                             // measurement aid (bench.py --debug 2048): staging only, forces are wrong
     for (int rb = 0; rb < iters; rb += 32 * NW)
     {
         uint32_t m[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int w = 0; w < NW; w++)
-        {
-            const int tb = rb + w * 32;
-            const int nb = min(32, iters - tb);            // multiple of 4, may be <= 0
-            uint32_t miss = 0xFFFFFFFFu;                   // one bit per candidate, 1 = outside the cut-off
-            if (LG == 4)
-            {   // 16 atoms x 4 slices: the distance filter of a block of 16 candidates x 16 atoms is ONE v_mfma_f32_16x16x4_f32:
-                //   D[cand][atom] = -|rj|^2 + (xj, yj, zj, 1) . (2 xi, 2 yi, 2 zi, thr - |ri|^2) = thr - |ri - rj|^2
-                // in f32 on cell-relative coordinates (|x| < cell/2 + rc), thr widened by the f32 error bound, so the filter stays
-                // conservative; pass 2 applies the exact fp64 test.  The matrix instruction holds the vector pipe for ~38 cycles per 256
-                // tests where the fp64 VALU form below needs ~140 (tools/ubench/valu_rates.hip); an fp64 MFMA would not help: it runs on
-                // the same fp64 units as v_fma_f64 (measured: additive).  Operand maps (gfx950): A[row l&15][k l>>4], B[k l>>4][col l&15],
-                // C/D[row 4 (l>>4) + reg][col l&15].  Rows are fed in the order perm(c) = (c >> 2) + 4 (c & 3), which makes register r of the
-                // lane (atom l&15, slice l>>4) the candidate 16 B + slice + 4 r: exactly the lane's own interleaved candidates; the
-                // -|rj|^2 of those four candidates arrive as the C operand.
-                const int lane = threadIdx.x & (kWave - 1);
-                const int c = lane & 15, k = lane >> 4;
-                const int permc = (c >> 2) + ((c & 3) << 2);
-                // lanes k = 3 feed the constant 1; they read (and ignore) the y array: banks 32-63, away from the z lanes of their half-wave
-                const double* pa = tx + (k == 3 ? 1 : k) * STRIDE + tb * NS + permc;
-                const float* pc = tw + tb * NS + k;        // -|rj|^2 of the lane's candidates k, k + 4, k + 8, k + 12 of every block
-                const int nblk = nb >> 2;                  // blocks of 16 candidates in this word (<= 8)
-#pragma unroll
-                for (int q = 0; q < 8; q++)
-                {
-                    if (q < nblk)
-                    {
-                        const float av = (float)pa[q * 16];
-                        const float a = (k == 3) ? 1.0f : av;
-                        const float4_t cw = {pc[q * 16], pc[q * 16 + 4], pc[q * 16 + 8], pc[q * 16 + 12]};      // two ds_read2_b32
-                        const float4_t d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, filtB, cw, 0, 0, 0);
-                        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[0]), 31);
-                        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[1]), 31);
-                        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[2]), 31);
-                        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[3]), 31);   // newest candidate in bit 0
-                    }
-                }
-                m[w] = (nb > 0) ? (~miss << (32 - nb)) : 0u;
-                continue;
-            }
-            const double* px = &tx[tb * NS + slice];
-            const double* py = &ty[tb * NS + slice];
-            const double* pz = &tz[tb * NS + slice];
-            for (int b = 0; b < nb; b += 4)
-            {
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                {
-                    // 7 VALU per candidate: 3 subtractions, 3 FMAs that leave d = rc^2(1+eps) - r^2, and one v_alignbit
-                    // that shifts the sign of d into the mask.  The filter is conservative by eps; pass 2 applies the
-                    // exact r^2 <= rc^2 test of the reference (pair_inter integrators.cpp:148).
-                    const double dx = xi - px[u * NS], dy = yi - py[u * NS], dz = zi - pz[u * NS];
-                    const double d = fma(-dz, dz, fma(-dy, dy, fma(-dx, dx, r2Filter)));
-                    miss = __builtin_amdgcn_alignbit(miss, (uint32_t)(__double_as_longlong(d) >> 32), 31);   // newest candidate in bit 0
-                }
-                px += 4 * NS; py += 4 * NS; pz += 4 * NS;
-            }
-            // left-align: candidate number b of this word sits at bit 31 - b, whatever the word length
-            m[w] = (nb > 0) ? (~miss << (32 - nb)) : 0u;
-        }
+        tile_filter<LG, STRIDE, NW>(tx, ty, tz, tw, rb, iters, slice, xi, yi, zi, filtB, r2Filter, m);
         // pass 2: every lane pops its own hits.  `cur` is the word being drained, `nxt`/`lst` the ones still waiting; when
         // `cur` runs dry the next word slides in (selects, no branches), so a lane keeps busy as long as ANY of its three
         // words has hits left - the wave loops max-over-lanes(hits per lane) times, not sum-over-words(max per word).
@@ -316,21 +319,6 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
         PairAcc& ra = acc;
         uint32_t cur = m[0], nxt = m[1], lst = m[2], ult = m[3];
         int kbase = rb * NS + slice;                       // tile index of bit 31 of `cur`
-        if (REC)
-        {   // where this lane's hits go in its atom's list: behind those of the lower slices (and of earlier rounds)
-            const int lane = threadIdx.x & (kWave - 1);
-            const int h = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
-            int below = 0, total = 0;
-#pragma unroll
-            for (int q = 0; q < NS; q++)
-            {
-                const int hq = __shfl(h, (lane & ((1 << LG) - 1)) | (q << LG), kWave);
-                below += (q < slice) ? hq : 0;
-                total += hq;
-            }
-            rec->pos = rec->base + below;
-            rec->base += total;
-        }
         if (__any((cur | nxt | lst | ult) != 0u))
         do
         {
@@ -348,14 +336,6 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
             const int b = __clz(cur | 1u);
             cur &= ~(0x80000000u >> b);                    // for a dry word this clears bit 0 of zero: harmless
             const int k = (kMaskBody || live) ? kbase + b * NS : T;       // dead lanes of the unmasked form: the first dummy
-            if (REC && live)
-            {   // entry e of the atom's list -> slice e mod NS, iteration e / NS
-                const int e = rec->pos++;
-                const int t = e >> (6 - LG);
-                const int dl = (threadIdx.x & ((1 << LG) - 1)) | ((e & (NS - 1)) << LG);
-                if (t < kListIters) rec->pl[((((t >> 3) << 6) + dl) << 3) + (t & 7)] = (uint16_t)(k << 3);
-                else rec->overflow = 1;
-            }
             const double dx = xi - tx[k], dy = yi - ty[k], dz = zi - tz[k];
             const double r2 = dx * dx + dy * dy + dz * dz;
             int tj = 0;
@@ -390,13 +370,20 @@ __device__ __forceinline__ int wave_max_int(int v)
     return v;
 }
 
-template <int MODE, int VDW, bool REC>   // MODE 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;
-                      // 3: as 2 with the real-space term of the Ewald sum ; 4: one species, surk with thermostat radii (case study 2).  REC: also record the lists
+template <int MODE, int VDW, bool CLEANUP>   // MODE 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;
+                      // 3: as 2 with the real-space term of the Ewald sum ; 4: one species, surk with thermostat radii (case study 2).
+                      // listMode 0: stage every cell ; 1: also record which candidates every tile held (the step that rebuilds the cells; k_build_lists then
+                      // makes the pair lists from them) ; 2: clean-up launch behind k_pair_list - a small grid that stages the cells without a list
 __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase,
-                                                     PairLists L, int onlyUnlisted)
+                                                     PairLists L, int listMode)
 {
+    const bool REC = !CLEANUP && listMode == 1;
+    constexpr bool onlyUnlisted = CLEANUP;           // (a template parameter: with the strided loop of the clean-up launch in it the full launch lost 7 %)
+    // recording launches only (dynamic LDS, kTileCap words): the candidates' list entries, written out in one piece when the cell is done.  Storing them one
+    // by one while staging cost 80 us on the 1 M-atom box: stores and loads share one in-order counter, so every group's loads waited for the last group's stores
+    extern __shared__ uint32_t tent[];
     // lazy re-sort (Engine::step): an atom has left the slack of the cell it was sorted into - until the next sort the stencil reaches one cell
     // further (rare; Engine::lazy_allowed guarantees that the wider stencil still sees every cell through one image only)
     const bool widened = P.lazySlack2 > 0.0 && P.nranks == 1 && counts->lazyViolated;     // (a slab rank has no ghost layers to widen into: Engine reports the violation)
@@ -415,7 +402,6 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
     __shared__ double trad[(MODE == 0 || MODE == 4) ? kTileLds : 1];
     __shared__ double pairTab[(MODE == 2 || MODE == 3) ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
     __shared__ int32_t entJ[kWave], entN[kWave], entC[kWave];       // staging table: first atom, count (<= 64), image-shift code
-    __shared__ uint4 tlist[REC ? kListStride16 / 8 : 1];            // recording launch: the cell's pair list in its final layout
 
     const int lane = threadIdx.x;
     PairAcc acc = {0, 0, 0, 0, 0, 0};
@@ -446,19 +432,21 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
     // has exactly one cell; the clean-up launch (a few workgroups that stride over all cells) takes those without a list - or, after a slack violation, all
     bool cleanupIdle = false;
     if (onlyUnlisted && !widened) cleanupIdle = L.noList[2] == 0;       // the last recording left no cell without a list: nothing to clean up
-    for (int rowBase = (int)(blockIdx.x >> 3); rowBase < per && !cleanupIdle; rowBase += kWave * rowStep)
+    for (int rowBase = (int)(blockIdx.x >> 3); rowBase < per && !cleanupIdle; rowBase += CLEANUP ? kWave * rowStep : per)
     {
-    unsigned long long todo;
+    unsigned long long todo = 1ULL;                                  // full launch: this workgroup's one cell
+    if (CLEANUP)
     {
         const int myRow = rowBase + lane * rowStep;
         const int myCr = (blockIdx.x & 7) * per + myRow;
         bool need = myRow < per && myCr < nCellsRun;
-        if (onlyUnlisted && !widened && need) need = L.meta[2 * (firstCell + myCr)] < 0;
+        if (!widened && need) need = L.meta[2 * (firstCell + myCr)] < 0;
         todo = __ballot(need);
     }
+    else if ((blockIdx.x & 7) * per + rowBase >= nCellsRun) todo = 0ULL;
     while (todo != 0ULL)
     {
-        const int rowK = __ffsll((long long)todo) - 1;
+        const int rowK = CLEANUP ? __ffsll((long long)todo) - 1 : 0;
         todo &= todo - 1ULL;
         const int cr = (blockIdx.x & 7) * per + rowBase + rowK * rowStep;
         const int cell = firstCell + cr;
@@ -479,17 +467,14 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
             const double w0 = (2 * P.hw[0] + 1) * h0, w1 = (2 * P.hw[1] + 1) * h1, w2 = (2 * P.hw[2] + 1) * h2;
             ext2 = w0 * w0 + w1 * w1 + w2 * w2;
         }
-        // a recording launch keeps every candidate within the list radius rc + 2 slack (= the pruning radius) in the masks; the forces still apply the exact test
-        const double r2Keep = (REC && !widened) ? P.pruneR2 : P.r2Max;
-        const double filtThr = r2Keep + 1.9073486328125e-06 * (4.0 * ext2 + r2Keep);      // 2^-19
+        const double filtThr = P.r2Max + 1.9073486328125e-06 * (4.0 * ext2 + P.r2Max);      // 2^-19
         // Lists (lazy re-sort): on the step that rebuilds the cells the staging below also records WHICH atoms it kept (index + image code, in tile
-        // order) and the passes record which of them every atom of the cell interacts with; until the next rebuild the atoms keep their slots and nobody
-        // moves farther than the slack the pruning radius already allows for, so the plain steps run k_pair_list: no run table, no pruning, no
-        // compaction, no distance filter.  Cells whose stencil needs more than one tile or that hold more than 64 atoms keep no list.
-        uint32_t* const myList = REC ? L.cand + (size_t)cell * kTileCap : nullptr;
+        // order), and k_build_lists then records which of them every atom of the cell interacts with; until the next rebuild the atoms keep their slots
+        // and nobody moves farther than the slack the pruning radius already allows for, so the plain steps run k_pair_list: no run table, no pruning,
+        // no compaction, no distance filter.  Cells whose stencil needs more than one tile or that hold more than 64 atoms keep no list.
+        uint32_t* const myList = L.cand + (size_t)cell * kTileCap;       // (only touched when recording)
         const bool record = REC && !widened && (ie - ib) <= kWave;
-        if (REC && !record && lane == 0) { L.meta[2 * cell] = -1; atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
-        if (REC && blockIdx.x == 0 && lane == 0) atomicAdd(&L.noList[1], nCellsRun);          // (one atomic per launch: 74 088 of them on one address cost 650 us)
+        if (REC && !record && lane == 0) L.meta[2 * cell] = -1;
         if (REC && record && ie == ib && lane == 0) L.meta[2 * cell] = 0;           // an empty cell: a list with nothing in it
         for (int i0 = ib; i0 < ie; i0 += kWave)
         {
@@ -515,15 +500,6 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
             acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0; acc.eV = 0.0; acc.eC = 0.0; acc.dropped = 0.0;
             int T = 0;
             bool flushed = false;                              // the stencil did not fit the tile in one piece
-            ListRec rec;
-            rec.pl = (uint16_t*)tlist;
-            if (REC && record)
-            {   // entries nobody writes read as offset 0: k_pair_list reads one candidate ahead of the one it evaluates
-                const uint4 zero4 = {0u, 0u, 0u, 0u};
-                for (int q = lane; q < kListStride16 / 8; q += kWave) tlist[q] = zero4;
-            }
-            rec.base = 0; rec.pos = 0; rec.overflow = 0;
-
             // one LDS chunk = two passes per round of 96 candidates per lane:
             //   pass 1  distance tests only (7 fp64 ops per candidate); hits are recorded in per-lane bit masks
             //   pass 2  every lane pops its own hits, so the expensive potential runs on densely filled waves
@@ -539,18 +515,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                     if (MODE == 0 || MODE == 4) trad[T + lane] = 1.0;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (REC && record)
-                {
-                    if (lg == 4) tile_passes<MODE, VDW, 4, kTileLds, 3, REC>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc, &rec);
-                    else if (lg == 5) tile_passes<MODE, VDW, 5, kTileLds, 3, REC>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc, &rec);
-                    else tile_passes<MODE, VDW, 6, kTileLds, 3, REC>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc, &rec);
-                }
-                else
-                {
-                    if (lg == 4) tile_passes<MODE, VDW, 4>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
-                    else if (lg == 5) tile_passes<MODE, VDW, 5>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
-                    else tile_passes<MODE, VDW, 6>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
-                }
+                if (lg == 4) tile_passes<MODE, VDW, 4>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
+                else if (lg == 5) tile_passes<MODE, VDW, 5>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
+                else tile_passes<MODE, VDW, 6>(P, S, pots, lj, tx, ty, tz, tw, ttyp, trad, pairTab, T, slice, xi, yi, zi, ti, radi, filtB, filtC, acc);
                 __builtin_amdgcn_wave_barrier();
                 T = 0;
             };
@@ -608,14 +575,23 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                     }
                     __builtin_amdgcn_wave_barrier();
                     int e = 0;
-                    bool tileFull = false;
                     while (e < nEnt)
                     {
-                        // tile full: run the passes on what is there, then go on filling (here, at the top, nothing of a group is live in registers)
-                        if (tileFull) { process(); flushed = true; tileFull = false; }
-                        const int g = min(4, nEnt - e);
+                        // up to four entries at a time, as many as are sure to fit: the tile must have room for all their atoms (counted before pruning - an
+                        // exact count per run, taken after the loads, cost 60-100 us on the 1 M-atom box: it chains the runs of a group one behind the other)
                         const int le = min(e + (lane & 3), nEnt - 1);
                         const int vj = entJ[le], vn = entN[le], vc = entC[le];
+                        int g = 0;
+                        {
+                            int room = kTileCap - T;
+#pragma unroll
+                            for (int u = 0; u < 4; u++)
+                            {
+                                const int nu = __builtin_amdgcn_readlane(vn, u);
+                                if (g == u && e + u < nEnt && nu <= room) { g = u + 1; room -= nu; }
+                            }
+                        }
+                        if (g == 0) { process(); flushed = true; continue; }   // tile full: run the passes on what is there, then go on filling
                         double gx[4], gy[4], gz[4], grad[4];
                         int gtyp[4], gjn[4], gcode[4];
 #pragma unroll
@@ -632,13 +608,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                                 if ((MODE == 0 && P.use_radii) || MODE == 4) grad[u] = ld_f64(A.rad, j);
                             }
                         }
-                        unsigned long long kmask[4];
-                        bool keepb[4];
-                        int nKeep = 0;
 #pragma unroll
                         for (int u = 0; u < 4; u++)
                         {
-                            kmask[u] = 0ULL; keepb[u] = false;
                             if (u < g)
                             {
                                 double xj = gx[u], yj = gy[u], zj = gz[u];
@@ -650,34 +622,22 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                                     zj += c2 == 0 ? -P.L[2] : (c2 == 2 ? P.L[2] : 0.0);
                                 }
                                 xj -= cc0; yj -= cc1; zj -= cc2;
-                                gx[u] = xj; gy[u] = yj; gz[u] = zj;
                                 // distance from the centre cell's box: atoms farther than the cut-off cannot reach any atom in it
                                 const double bx = fmax(fabs(xj) - h0, 0.0);
                                 const double by = fmax(fabs(yj) - h1, 0.0);
                                 const double bz = fmax(fabs(zj) - h2, 0.0);
                                 const bool keep = (lane < gjn[u]) && (bx * bx + by * by + bz * bz) <= P.pruneR2;
-                                keepb[u] = keep;
-                                kmask[u] = __ballot(keep);
-                                nKeep += __popcll(kmask[u]);
-                            }
-                        }
-                        if (T + nKeep > kTileCap) { tileFull = true; continue; }      // what this group really adds does not fit: flush, then stage the group again
-#pragma unroll
-                        for (int u = 0; u < 4; u++)
-                        {
-                            if (u < g)
-                            {
-                                if (keepb[u])
+                                const unsigned long long mask = __ballot(keep);
+                                if (keep)
                                 {
-                                    const double xj = gx[u], yj = gy[u], zj = gz[u];
-                                    const int pp = T + lanes_below(kmask[u]);
+                                    const int pp = T + lanes_below(mask);
                                     tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
                                     tw[pp] = -(float)(xj * xj + yj * yj + zj * zj);
-                                    if (REC && record) myList[pp] = (uint32_t)(__builtin_amdgcn_readlane(vj, u) + lane) | ((uint32_t)gcode[u] << 26);
+                                    if (REC && record) tent[pp] = (uint32_t)(__builtin_amdgcn_readlane(vj, u) + lane) | ((uint32_t)gcode[u] << 26);
                                     if (!kOneSpecies) ttyp[pp] = (uint8_t)gtyp[u];
                                     if (MODE == 0 || MODE == 4) trad[pp] = grad[u];
                                 }
-                                T += __popcll(kmask[u]);
+                                T += __popcll(mask);
                             }
                         }
                         e += g;
@@ -688,26 +648,13 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
             const int Tfin = T;
             process();
             if (REC && record)
-            {   // what the plain steps need to know about this cell
-                const int nMine = rec.base;                                     // entries of this lane's atom (idle atom slots: none)
-                const int ls = 6 - lg, ns = 1 << ls;                             // log2(slices), slices
-                const int nIter = wave_max_int((nMine + ns - 1) >> ls);
-                const bool usable = !flushed && nIter <= kListIters && !__any(rec.overflow != 0);
-                L.laneCnt[(size_t)cell * kWave + lane] = (uint8_t)max(0, (nMine - slice + ns - 1) >> ls);
-                if (usable)
-                {
-                    uint4* const out = (uint4*)(L.pairs + (size_t)cell * kListStride16);
-                    for (int c = 0; c * 8 < nIter; c++) out[c * kWave + lane] = tlist[c * kWave + lane];
-                }
-                // the plain steps gather whole groups of 64 candidates: fill the last group with a valid atom (the cell's first) - its copies land behind
-                // the candidates any list entry points at
+            {   // the header k_build_lists starts from: the number of candidates, or "no list" when the stencil did not fit one tile.  The plain steps gather
+                // whole groups of 64 candidates: the last group is filled with a valid atom (the cell's first) - its copies land behind the candidates any
+                // list entry points at
                 const int Tpad = (Tfin + kWave - 1) & ~(kWave - 1);
-                if (usable && Tfin + lane < Tpad) myList[Tfin + lane] = (uint32_t)ib | (0x15u << 26);
-                if (lane == 0)
-                {
-                    L.meta[2 * cell] = usable ? (Tfin | (nIter << 12)) : -1;
-                    if (!usable) { atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
-                }
+                if (!flushed)
+                    for (int q = lane; q < Tpad; q += kWave) myList[q] = (q < Tfin) ? tent[q] : ((uint32_t)ib | (0x15u << 26));
+                if (lane == 0) L.meta[2 * cell] = flushed ? -1 : Tfin;
             }
 
             // fold the j-slices (fixed order) and write the force: clear_force + pair sums
@@ -773,12 +720,12 @@ inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const D
 {
     pair_range_default(P, R);
     if (R.n == 0) return;
-    if (listMode == 1)
-        hipLaunchKernelGGL((k_pair_tile<MODE, VDW, true>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt,
-                           R.blockBase, L, 0);
+    if (listMode == 2)
+        hipLaunchKernelGGL((k_pair_tile<MODE, VDW, true>), dim3(pair_cleanup_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
+                           cnt, R.blockBase, L, listMode);
     else
-        hipLaunchKernelGGL((k_pair_tile<MODE, VDW, false>), dim3(listMode == 2 ? pair_cleanup_grid(R.n) : pair_range_grid(R.n)), dim3(kWave), 0, stream,
-                           P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt, R.blockBase, L, listMode == 2 ? 1 : 0);
+        hipLaunchKernelGGL((k_pair_tile<MODE, VDW, false>), dim3(pair_range_grid(R.n)), dim3(kWave), listMode == 1 ? sizeof(uint32_t) * kTileCap : 0, stream, P, S, pots, A,
+                           cellStart, R.first, R.n, partials, maxBlocks, cnt, R.blockBase, L, listMode);
 }
 
 // dispatch on the potential set.  P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs; 5 = a mix of

@@ -159,6 +159,8 @@ typedef struct
                                         (engElec1, ewald_const elec.cpp:144 ; engCoul3); engCoul above is the real-space part */
     int64_t sort_interval;       /* steps between two rebuilds of the cell list that the next aztot_step call will use (1: every step) */
     int64_t sort_violations;     /* calls so far in which an atom left its cell's slack before the scheduled rebuild (handled exactly, by a wider stencil) */
+    int64_t pair_lists;          /* 1: the steps between two rebuilds walk per-atom pair lists recorded at the rebuild (k_pair_list) ; 0: they stage every cell */
+    int64_t cells_without_list;  /* cells whose stencil did not fit one tile / with more partners than a list holds at the last rebuild: staged in full */
 } aztot_stats;
 
 /* host copy of the per-atom state, fp64 SoA, in ORIGINAL atom order (id order); any pointer may be NULL */

@@ -530,6 +530,48 @@ def test_lazy_resort_is_exact(mode, variant):
     assert a.stats()["posCross"] == sta["posCross"]
 
 
+@pytest.mark.parametrize("kind", ["lj", "lj_fennell", "buck", "elin", "part_unlisted", "dense_cells"])
+def test_pair_lists_between_two_rebuilds(kind):
+    """The steps between two rebuilds of the cell list walk the pair lists the rebuild recorded (k_build_lists -> k_pair_list) instead of staging and
+    filtering every cell again: same forces as the every-step schedule (summation order aside) and as the oracle.  'part_unlisted': debug bit 65536
+    caps the lists at 14 iterations, so part of the cells keep no list and go through the clean-up launch of the staging kernel while the others
+    walk their lists; 'dense_cells': cells of 3 rc hold ~108 atoms (> 64: no cell keeps a list, everything goes through the clean-up launch until the
+    engine notices and stops recording)."""
+    kw = {}
+    if kind in ("lj", "part_unlisted"):
+        case = inputs.lj_case((8, 8, 8), a=5.6, seed=31, rc=7.5, cell_list=7.9, vel_T=120.0)
+        if kind == "part_unlisted":
+            kw = dict(debug=65536)
+    elif kind == "lj_fennell":
+        case = inputs.lj_case((8, 8, 8), a=5.6, seed=32, rc=7.5, cell_list=7.9, vel_T=120.0, charges=(0.3, -0.3), elec="fenn", r_real=7.5, alpha=0.3)
+    elif kind in ("buck", "elin"):           # one potential family in the LDS table / the generic switch-based body
+        case = mixed_case(kind, n=8, seed=5)
+    else:
+        case = inputs.lj_case((15, 15, 15), a=5.6, seed=33, rc=5.5, cell_list=16.5, vel_T=120.0)        # 5 cells of 16.8 A per axis, 108 atoms each
+    a = engine(case, pair_variant=2, **kw)
+    b = engine(case, pair_variant=2, sort_every=1)
+    o = oracle.Oracle(case)
+    o.forces(1)
+    for n in (10, 30, 7):
+        a.step(n); b.step(n); o.step(n)
+    sa, sb, so, sta, stb, sto = a.state(), b.state(), o.state(), a.stats(), b.stats(), o.stats()
+    assert sta["sort_interval"] > 1 and sta["sort_violations"] == 0, sta
+    if kind == "dense_cells":
+        assert sta["pair_lists"] == 0                     # nothing kept a list: the engine went back to staging every cell
+    else:
+        assert sta["pair_lists"] == 1
+        if kind == "part_unlisted":
+            assert 0 < sta["cells_without_list"] < sta["n_cells"], sta
+        else:
+            assert sta["cells_without_list"] == 0, sta
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(sa[k], sb[k]) < 1e-9, (k, rel_err(sa[k], sb[k]))
+        assert rel_err(sa[k], so[k]) < 1e-9, (k, rel_err(sa[k], so[k]))
+    for k in ("engVdW", "engCoul", "engKin", "engTot"):
+        assert abs(sta[k] - stb[k]) <= 1e-10 * max(abs(stb[k]), 1e-3), (k, sta[k], stb[k])
+    assert abs(sta["engTot"] - sto["engTot"]) <= 1e-10 * abs(sto["engTot"])
+
+
 def test_tile_and_atom_kernels_agree_bitwise_on_energy_scale():
     case = inputs.config("F3")
     a, b = engine(case, pair_variant=1), engine(case, pair_variant=2)
