@@ -674,17 +674,19 @@ void Engine::launch_pair()
         else
         {
             splitBlocks_ = 0;
-            if (candMode_ == 2 && pl.cand)       // plain step of the lazy re-sort: walk the lists; the clean-up launch stages what keeps none
-            {
+            if (candMode_ != 0 && pl.cand)
+            {   // lazy re-sort.  The step that rebuilds the cells first makes the lists (candidates of every tile, partners of every atom); then, like every
+                // plain step until the next rebuild, it walks them; the clean-up launch stages the cells that keep no list
+                if (candMode_ == 1)
+                {
+                    HIP_CHECK(hipMemsetAsync(dNoList_ + 2, 0, sizeof(int32_t), stream_));     // cells without a list: counted anew
+                    timed("build_lists", [&] { launch_build_lists(Q, S_, dPots_, cur(), dCounts_, dCellStart_, stream_, PairRange(), pl); });
+                }
                 timed("pair_list", [&] { splitBlocks_ = launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl); });
                 timed("pair_cleanup", [&] { splitBlocks_ += launch_pair_cleanup(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl); });
             }
             else
-            {
-                if (candMode_ == 1 && pl.cand) HIP_CHECK(hipMemsetAsync(dNoList_ + 2, 0, sizeof(int32_t), stream_));     // cells without a list: counted anew
-                timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, candMode_ == 1 ? 1 : 0); });
-                if (candMode_ == 1 && pl.cand) timed("build_lists", [&] { launch_build_lists(Q, cur(), dCellStart_, stream_, PairRange(), pl); });
-            }
+                timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, 0); });
         }
     }
     else

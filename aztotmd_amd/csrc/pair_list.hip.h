@@ -216,185 +216,6 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------------
-// The pair lists are made on the step that rebuilds the cells, right behind k_pair_tile (which computed that step's forces and recorded the candidates
-// of every tile): gather the candidates again, run the distance filter of k_pair_tile's pass 1 with the LIST radius rc + 2 slack, and deal every
-// atom's hits round-robin to the lanes that serve it.  Independent of the potential set (geometry only).  A separate kernel on purpose: recording
-// inside the force kernel cost it a third of its occupancy (+30 VGPRs, +4 KiB of LDS) and doubled the time of the rebuild step.
-// ------------------------------------------------------------------------------------------------------------------------------------
-template <int LG>
-__device__ __forceinline__ void deal_hits(const double* tx, const double* ty, const double* tz, const float* tw, uint4* tlist, int T, int slice, double xi, double yi,
-                                          double zi, float filtB, double r2List, int& nMine, int& overflow)
-{
-    constexpr int NS = kWave >> LG;
-    constexpr int NR = (LG == 4) ? 1 : (LG == 5 ? 2 : 4);         // rounds of 96 candidates per lane that cover a full tile (320 / NS per lane)
-    const int lane = threadIdx.x & (kWave - 1);
-    const int il = lane & ((1 << LG) - 1);
-    const int iters = ((T + NS - 1) / NS + 3) & ~3;
-    // phase A: all distance tests; the hit masks of the whole tile stay in registers
-    uint32_t mm[3 * NR];
-#pragma unroll
-    for (int r = 0; r < NR; r++)
-    {
-        uint32_t m[4] = {0u, 0u, 0u, 0u};
-        if (r * 96 < iters) tile_filter<LG, kTileLds, 3>(tx, ty, tz, tw, r * 96, iters, slice, xi, yi, zi, filtB, r2List, m);
-        mm[3 * r] = m[0]; mm[3 * r + 1] = m[1]; mm[3 * r + 2] = m[2];
-    }
-    // phase B: the tile is no longer needed - the list is assembled in its place.  Entries nobody writes read as offset 0 (k_pair_list reads one
-    // candidate ahead of the one it evaluates)
-    __builtin_amdgcn_wave_barrier();
-    const uint4 zero4 = {0u, 0u, 0u, 0u};
-    for (int q = lane; q < kListStride16 / 8; q += kWave) tlist[q] = zero4;
-    __builtin_amdgcn_wave_barrier();
-    uint16_t* const tl = (uint16_t*)tlist;
-    // where this lane's hits go in its atom's list: behind those of the lower slices
-    int h = 0;
-#pragma unroll
-    for (int w = 0; w < 3 * NR; w++) h += __popc(mm[w]);
-    int below = 0, total = 0;
-#pragma unroll
-    for (int q = 0; q < NS; q++)
-    {
-        const int hq = __shfl(h, il | (q << LG), kWave);
-        below += (q < slice) ? hq : 0;
-        total += hq;
-    }
-    int e = below;
-#pragma unroll
-    for (int w = 0; w < 3 * NR; w++)
-    {
-        uint32_t cur = mm[w];
-        const int kbase = 32 * w * NS + slice;                 // tile index of bit 31 of this word
-        while (cur != 0u)
-        {   // entry e of the atom's list -> slice e mod NS, iteration e / NS ; an entry is the candidate's byte offset in the LDS tile
-            const int b = __clz(cur);
-            cur &= ~(0x80000000u >> b);
-            const int k = kbase + b * NS;
-            const int t = e >> (6 - LG);
-            const int dl = il | ((e & (NS - 1)) << LG);
-            if (t < kListIters) tl[((((t >> 3) << 6) + dl) << 3) + (t & 7)] = (uint16_t)(k << 3);
-            else overflow = 1;
-            e++;
-        }
-    }
-    nMine = total;
-}
-
-__global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, AtomArrays A, const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun, PairLists L)
-{
-    __shared__ double txyz[3 * kTileLds];                           // the tile; later, in its place, the cell's pair list in its final layout
-    __shared__ float tw[kTileLds];
-    static_assert(sizeof(double) * 3 * kTileLds >= sizeof(uint16_t) * kListStride16, "the list is assembled where the tile was");
-    uint4* const tlist = (uint4*)txyz;
-    const int lane = threadIdx.x;
-    const int per = (nCellsRun + 7) >> 3;
-    const int cr = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (blockIdx.x == 0 && lane == 0) atomicAdd(&L.noList[1], nCellsRun);          // cells recorded (one atomic per launch: one per cell on one address cost 650 us)
-    if (cr >= nCellsRun) return;
-    const int cell = firstCell + cr;
-    const uint32_t* const myList = L.cand + (size_t)cell * kTileCap + lane;
-    constexpr int kRounds = kTileCap / kWave;
-    uint32_t ent[kRounds];
-#pragma unroll
-    for (int u = 0; u < kRounds - 1; u++) ent[u] = myList[u * kWave];
-    const int2 mx = ((const int2*)L.meta)[cell];                   // {T as k_pair_tile left it (-1: the stencil did not fit one tile), cell coordinates}
-    const int T = mx.x;
-    if (T <= 0)
-    {
-        if (T < 0 && lane == 0) { atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
-        return;
-    }
-    const int ncy = P.nc[1], ncz = P.nc[2];
-    const int lx = mx.y & 1023, cy = (mx.y >> 10) & 1023, cz = (mx.y >> 20) & 1023;
-    const int ib = cellStart[cell], ie = cellStart[cell + 1];
-    const double h0 = 0.5 * P.csz[0], h1 = 0.5 * P.csz[1], h2 = 0.5 * P.csz[2];
-    const double cc0 = (lx + P.cx0) * P.csz[0] + h0, cc1 = cy * P.csz[1] + h1, cc2 = cz * P.csz[2] + h2;
-    const int nthis = ie - ib;                                     // 1 .. 64
-    const int lg = nthis <= 16 ? 4 : (nthis <= 32 ? 5 : 6);
-    const int il = lane & ((1 << lg) - 1), slice = lane >> lg;
-    const bool validI = il < nthis;
-    const int myl = validI ? ib + il : ib;
-    const double xr = A.x[myl], yr = A.y[myl], zr = A.z[myl];
-    {   // gather the candidates, as k_pair_list does, plus -|r|^2 in f32 for the matrix filter
-        const int rounds = (T + kWave - 1) >> 6;
-        const int gx0 = lx + P.cx0;
-        const bool images = gx0 - P.hw[0] < 0 || gx0 + P.hw[0] >= P.nc[0] || cy - P.hw[1] < 0 || cy + P.hw[1] >= ncy || cz - P.hw[2] < 0 || cz + P.hw[2] >= ncz;
-        double gx[kRounds], gy[kRounds], gz[kRounds];
-        ent[kRounds - 1] = 0u;
-        if (rounds == kRounds) ent[kRounds - 1] = myList[(kRounds - 1) * kWave];
-#pragma unroll
-        for (int u = 0; u < kRounds; u++)
-            if (u < kRounds - 1 || rounds == kRounds)
-            {
-                const int j = (int)(ent[u] & 0x3FFFFFFu);
-                gx[u] = ld_f64(A.x, j); gy[u] = ld_f64(A.y, j); gz[u] = ld_f64(A.z, j);
-            }
-#pragma unroll
-        for (int u = 0; u < kRounds; u++)
-            if (u < kRounds - 1 || rounds == kRounds)
-            {
-                double xj = gx[u], yj = gy[u], zj = gz[u];
-                if (images)
-                {
-                    const int c0 = (ent[u] >> 26) & 3, c1 = (ent[u] >> 28) & 3, c2 = (ent[u] >> 30) & 3;
-                    xj += c0 == 0 ? -P.L[0] : (c0 == 2 ? P.L[0] : 0.0);
-                    yj += c1 == 0 ? -P.L[1] : (c1 == 2 ? P.L[1] : 0.0);
-                    zj += c2 == 0 ? -P.L[2] : (c2 == 2 ? P.L[2] : 0.0);
-                }
-                xj -= cc0; yj -= cc1; zj -= cc2;
-                const int pq = u * kWave + lane;
-                const bool real = pq < T;                           // behind the last candidate: far-away dummies, never a hit
-                txyz[pq] = real ? xj : -1e30; txyz[kTileLds + pq] = real ? yj : 0.0; txyz[2 * kTileLds + pq] = real ? zj : 0.0;
-                tw[pq] = real ? -(float)(xj * xj + yj * yj + zj * zj) : -3e38f;
-            }
-        if (lane < kTilePad)
-        {   // the unrolled filter may touch up to 15 entries behind the last candidate (groups of 64 end exactly there when T is a multiple of 64)
-            const int pq = T + lane;
-            txyz[pq] = -1e30; txyz[kTileLds + pq] = 0.0; txyz[2 * kTileLds + pq] = 0.0; tw[pq] = -3e38f;
-        }
-    }
-    const double xi = validI ? xr - cc0 : 1e30, yi = validI ? yr - cc1 : 1e30, zi = validI ? zr - cc2 : 1e30;
-    // list radius rc + 2 slack (= the pruning radius of the tile); f32 filter threshold widened by the error bound exactly as in k_pair_tile
-    const double rprune = sqrt(P.pruneR2), rcut = rprune + 0.5 * (rprune - sqrt(P.r2Max));
-    const double ext2 = (h0 + rcut) * (h0 + rcut) + (h1 + rcut) * (h1 + rcut) + (h2 + rcut) * (h2 + rcut);
-    const double filtThr = P.pruneR2 + 1.9073486328125e-06 * (4.0 * ext2 + P.pruneR2);      // 2^-19
-    const float filtB = (slice == 0) ? (float)(2.0 * xi) : (slice == 1) ? (float)(2.0 * yi) : (slice == 2) ? (float)(2.0 * zi)
-                                                                                            : (float)(filtThr - (xi * xi + yi * yi + zi * zi));
-    const double r2List = P.pruneR2 * (1.0 + 1e-13);
-    __builtin_amdgcn_wave_barrier();
-    int nMine = 0, overflow = 0;
-    const double* const tx = txyz;
-    const double* const ty = txyz + kTileLds;
-    const double* const tz = txyz + 2 * kTileLds;
-    if (lg == 4) deal_hits<4>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, filtB, r2List, nMine, overflow);
-    else if (lg == 5) deal_hits<5>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, filtB, r2List, nMine, overflow);
-    else deal_hits<6>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, filtB, r2List, nMine, overflow);
-    __builtin_amdgcn_wave_barrier();
-    // what the plain steps need to know about this cell
-    const int ls = 6 - lg, ns = 1 << ls;                             // log2(slices), slices
-    const int nIter = wave_max_int((nMine + ns - 1) >> ls);
-    // (debug bit 65536, tests: lists hold 14 iterations only - on a liquid part of the cells then keep no list and go through the clean-up launch)
-    const bool usable = nIter <= ((P.pad0 & 65536) ? 14 : kListIters) && !__any(overflow != 0);
-    if (usable)
-    {
-        L.laneCnt[(size_t)cell * kWave + lane] = (uint8_t)max(0, (nMine - slice + ns - 1) >> ls);
-        uint4* const out = (uint4*)(L.pairs + (size_t)cell * kListStride16);
-        for (int c = 0; c * 8 < nIter; c++) out[c * kWave + lane] = tlist[c * kWave + lane];
-    }
-    if (lane == 0)
-    {
-        L.meta[2 * cell] = usable ? (T | (nIter << 12)) : -1;
-        if (!usable) { atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
-    }
-}
-
-inline void launch_build_lists(const StepParams& P, AtomArrays A, const int32_t* cellStart, hipStream_t stream, PairRange R, PairLists L)
-{
-    pair_range_default(P, R);
-    if (R.n == 0) return;
-    hipLaunchKernelGGL(k_build_lists, dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, A, cellStart, R.first, R.n, L);
-}
-
 template <int MODE, int VDW>
 inline void launch_pair_list_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
                                 int maxBlocks, hipStream_t stream, PairRange R, PairLists L)

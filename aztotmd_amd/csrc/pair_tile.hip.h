@@ -350,6 +350,66 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
     if (MODE != 0) acc.dropped += 0.5 * (double)nDropHalf;     // dropped pairs, counted per lane in "half pair" units (every pair is visited from both ends)
 }
 
+// Making the pair lists (the BUILD instantiation of k_pair_tile, on the step that rebuilds the cells): the distance filter of pass 1 with the LIST radius
+// rc + 2 slack, then every atom's hits are dealt round-robin to the lanes that serve it.  Geometry only - independent of the potential set.
+template <int LG>
+__device__ __forceinline__ void deal_hits(const double* tx, const double* ty, const double* tz, const float* tw, uint4* tlist, int T, int slice, double xi, double yi,
+                                          double zi, float filtB, double r2List, int& nMine, int& overflow)
+{
+    constexpr int NS = kWave >> LG;
+    constexpr int NR = (LG == 4) ? 1 : (LG == 5 ? 2 : 4);         // rounds of 96 candidates per lane that cover a full tile (320 / NS per lane)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int il = lane & ((1 << LG) - 1);
+    const int iters = ((T + NS - 1) / NS + 3) & ~3;
+    // phase A: all distance tests; the hit masks of the whole tile stay in registers
+    uint32_t mm[3 * NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+    {
+        uint32_t m[4] = {0u, 0u, 0u, 0u};
+        if (r * 96 < iters) tile_filter<LG, kTileLds, 3>(tx, ty, tz, tw, r * 96, iters, slice, xi, yi, zi, filtB, r2List, m);
+        mm[3 * r] = m[0]; mm[3 * r + 1] = m[1]; mm[3 * r + 2] = m[2];
+    }
+    // phase B: the tile is no longer needed - the list is assembled in its place.  Entries nobody writes read as offset 0 (k_pair_list reads one
+    // candidate ahead of the one it evaluates)
+    __builtin_amdgcn_wave_barrier();
+    const uint4 zero4 = {0u, 0u, 0u, 0u};
+    for (int q = lane; q < kListStride16 / 8; q += kWave) tlist[q] = zero4;
+    __builtin_amdgcn_wave_barrier();
+    uint16_t* const tl = (uint16_t*)tlist;
+    // where this lane's hits go in its atom's list: behind those of the lower slices
+    int h = 0;
+#pragma unroll
+    for (int w = 0; w < 3 * NR; w++) h += __popc(mm[w]);
+    int below = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+    {
+        const int hq = __shfl(h, il | (q << LG), kWave);
+        below += (q < slice) ? hq : 0;
+        total += hq;
+    }
+    int e = below;
+#pragma unroll
+    for (int w = 0; w < 3 * NR; w++)
+    {
+        uint32_t cur = mm[w];
+        const int kbase = 32 * w * NS + slice;                 // tile index of bit 31 of this word
+        while (cur != 0u)
+        {   // entry e of the atom's list -> slice e mod NS, iteration e / NS ; an entry is the candidate's byte offset in the LDS tile
+            const int b = __clz(cur);
+            cur &= ~(0x80000000u >> b);
+            const int k = kbase + b * NS;
+            const int t = e >> (6 - LG);
+            const int dl = il | ((e & (NS - 1)) << LG);
+            if (t < kListIters) tl[((((t >> 3) << 6) + dl) << 3) + (t & 7)] = (uint16_t)(k << 3);
+            else overflow = 1;
+            e++;
+        }
+    }
+    nMine = total;
+}
+
 // Lists of the lazy re-sort, written by the recording launch of k_pair_tile and read by k_pair_list (pair_list.hip.h)
 struct PairLists
 {
@@ -370,20 +430,22 @@ __device__ __forceinline__ int wave_max_int(int v)
     return v;
 }
 
-template <int MODE, int VDW, bool CLEANUP>   // MODE 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;
+template <int MODE, int VDW, bool CLEANUP, bool BUILD = false>
+                      // MODE 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;
                       // 3: as 2 with the real-space term of the Ewald sum ; 4: one species, surk with thermostat radii (case study 2).
-                      // listMode 0: stage every cell ; 1: also record which candidates every tile held (the step that rebuilds the cells; k_build_lists then
-                      // makes the pair lists from them) ; 2: clean-up launch behind k_pair_list - a small grid that stages the cells without a list
+                      // CLEANUP: the clean-up launch behind k_pair_list - a small grid that strides over the cells and stages those without a list.
+                      // BUILD (instantiated once, <1, 1, false, true>; the step that rebuilds the cells): no forces - stage every cell as usual, record the
+                      // candidates its tile holds and make the pair lists from them; k_pair_list then computes that step's forces like any other's
 __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase,
-                                                     PairLists L, int listMode)
+                                                     PairLists L)
 {
-    const bool REC = !CLEANUP && listMode == 1;
+    constexpr bool REC = BUILD;
     constexpr bool onlyUnlisted = CLEANUP;           // (a template parameter: with the strided loop of the clean-up launch in it the full launch lost 7 %)
-    // recording launches only (dynamic LDS, kTileCap words): the candidates' list entries, written out in one piece when the cell is done.  Storing them one
-    // by one while staging cost 80 us on the 1 M-atom box: stores and loads share one in-order counter, so every group's loads waited for the last group's stores
-    extern __shared__ uint32_t tent[];
+    // BUILD: the candidates' list entries, written out in one piece when the cell is done (stored one by one while staging they cost 80 us on the 1 M-atom
+    // box: stores and loads share one in-order counter, so every group's loads waited for the last group's stores)
+    __shared__ uint32_t tent[BUILD ? kTileCap : 1];
     // lazy re-sort (Engine::step): an atom has left the slack of the cell it was sorted into - until the next sort the stencil reaches one cell
     // further (rare; Engine::lazy_allowed guarantees that the wider stencil still sees every cell through one image only)
     const bool widened = P.lazySlack2 > 0.0 && P.nranks == 1 && counts->lazyViolated;     // (a slab rank has no ghost layers to widen into: Engine reports the violation)
@@ -474,8 +536,16 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
         // no compaction, no distance filter.  Cells whose stencil needs more than one tile or that hold more than 64 atoms keep no list.
         uint32_t* const myList = L.cand + (size_t)cell * kTileCap;       // (only touched when recording)
         const bool record = REC && !widened && (ie - ib) <= kWave;
-        if (REC && !record && lane == 0) L.meta[2 * cell] = -1;
-        if (REC && record && ie == ib && lane == 0) L.meta[2 * cell] = 0;           // an empty cell: a list with nothing in it
+        if (BUILD)
+        {
+            if (blockIdx.x == 0 && lane == 0) atomicAdd(&L.noList[1], nCellsRun);      // cells recorded (one atomic per launch: one per cell on one address cost 650 us)
+            if (ie == ib) { if (lane == 0) L.meta[2 * cell] = 0; continue; }          // an empty cell: a list with nothing in it
+            if (!record)
+            {   // more than 64 atoms: the cell keeps no list
+                if (lane == 0) { L.meta[2 * cell] = -1; atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
+                continue;
+            }
+        }
         for (int i0 = ib; i0 < ie; i0 += kWave)
         {
             const int nthis = min(kWave, ie - i0);
@@ -506,6 +576,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
             //           (about 20 % of the candidates are inside the cut-off: evaluating the potential inline would
             //            execute it for nearly every wave-iteration with 80 % of the lanes masked off)
             auto process = [&]() {
+                if (BUILD) { T = 0; return; }                 // (tile full before the stencil is through: this cell will keep no list)
                 // far-away, FINITE dummies behind the last candidate: the passes need no bounds checks, and dead lanes have a
                 // harmless candidate to chew on (uninitialised LDS could hold NaN patterns: 0 * NaN would poison a force)
                 if (lane < kTilePad)
@@ -633,7 +704,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                                     const int pp = T + lanes_below(mask);
                                     tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
                                     tw[pp] = -(float)(xj * xj + yj * yj + zj * zj);
-                                    if (REC && record) tent[pp] = (uint32_t)(__builtin_amdgcn_readlane(vj, u) + lane) | ((uint32_t)gcode[u] << 26);
+                                    if (BUILD) tent[pp] = (uint32_t)(__builtin_amdgcn_readlane(vj, u) + lane) | ((uint32_t)gcode[u] << 26);
                                     if (!kOneSpecies) ttyp[pp] = (uint8_t)gtyp[u];
                                     if (MODE == 0 || MODE == 4) trad[pp] = grad[u];
                                 }
@@ -645,17 +716,50 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            const int Tfin = T;
-            process();
-            if (REC && record)
-            {   // the header k_build_lists starts from: the number of candidates, or "no list" when the stencil did not fit one tile.  The plain steps gather
-                // whole groups of 64 candidates: the last group is filled with a valid atom (the cell's first) - its copies land behind the candidates any
-                // list entry points at
-                const int Tpad = (Tfin + kWave - 1) & ~(kWave - 1);
-                if (!flushed)
-                    for (int q = lane; q < Tpad; q += kWave) myList[q] = (q < Tfin) ? tent[q] : ((uint32_t)ib | (0x15u << 26));
-                if (lane == 0) L.meta[2 * cell] = flushed ? -1 : Tfin;
+            if (BUILD)
+            {
+                bool usable = !flushed;
+                int nIter = 0;
+                if (usable)
+                {
+                    // the plain steps gather whole groups of 64 candidates: the last group is filled with a valid atom (the cell's first) - its copies land
+                    // behind the candidates any list entry points at
+                    const int Tpad = (T + kWave - 1) & ~(kWave - 1);
+                    for (int q = lane; q < Tpad; q += kWave) myList[q] = (q < T) ? tent[q] : ((uint32_t)ib | (0x15u << 26));
+                    if (lane < kTilePad) { tx[T + lane] = -1e30; ty[T + lane] = 0.0; tz[T + lane] = 0.0; tw[T + lane] = -3e38f; }     // dummies, as in process()
+                    __builtin_amdgcn_wave_barrier();
+                    // list radius rc + 2 slack (= the pruning radius of the tile); f32 threshold widened by the error bound like filtThr above
+                    const double thrList = P.pruneR2 + 1.9073486328125e-06 * (4.0 * ext2 + P.pruneR2);
+                    const float fB = (slice == 0) ? (float)(2.0 * xi) : (slice == 1) ? (float)(2.0 * yi) : (slice == 2) ? (float)(2.0 * zi)
+                                                                                     : (float)(thrList - (xi * xi + yi * yi + zi * zi));
+                    const double r2List = P.pruneR2 * (1.0 + 1e-13);
+                    int nMine = 0, overflow = 0;
+                    uint4* const tlist = (uint4*)txyz;             // the list is assembled where the tile was
+                    static_assert(sizeof(double) * 3 * kTileLds >= sizeof(uint16_t) * kListStride16, "the list is assembled where the tile was");
+                    if (lg == 4) deal_hits<4>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, nMine, overflow);
+                    else if (lg == 5) deal_hits<5>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, nMine, overflow);
+                    else deal_hits<6>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, nMine, overflow);
+                    __builtin_amdgcn_wave_barrier();
+                    const int ls = 6 - lg, ns = 1 << ls;                             // log2(slices), slices
+                    nIter = wave_max_int((nMine + ns - 1) >> ls);
+                    // (debug bit 65536, tests: lists hold 14 iterations only - on a liquid part of the cells then keep no list and go through the clean-up launch)
+                    usable = nIter <= ((P.pad0 & 65536) ? 14 : kListIters) && !__any(overflow != 0);
+                    if (usable)
+                    {
+                        L.laneCnt[(size_t)cell * kWave + lane] = (uint8_t)max(0, (nMine - slice + ns - 1) >> ls);
+                        uint4* const out = (uint4*)(L.pairs + (size_t)cell * kListStride16);
+                        for (int c = 0; c * 8 < nIter; c++) out[c * kWave + lane] = tlist[c * kWave + lane];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (lane == 0)
+                {
+                    L.meta[2 * cell] = usable ? (T | (nIter << 12)) : -1;
+                    if (!usable) { atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
+                }
+                continue;                                          // no forces here: k_pair_list computes them
             }
+            process();
 
             // fold the j-slices (fixed order) and write the force: clear_force + pair sums
             for (int o = kWave >> 1; o >= islots; o >>= 1)
@@ -685,6 +789,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
         }
     }
     }   // batches of rows
+    if (BUILD) return;
     eV = wave_sum(eV); eC = wave_sum(eC); dropped = wave_sum(dropped);
     if (lane == 0)
     {
@@ -713,7 +818,7 @@ inline void pair_range_default(const StepParams& P, PairRange& R)
     if (R.n < 0) { R.n = pair_tile_cells(P); R.first = (P.nranks > 1) ? P.hw[0] * plane : 0; R.blockBase = 0; }
 }
 
-// listMode 0: stage every cell ; 1: stage every cell and record the lists ; 2: clean-up launch - a small grid that stages the cells without a list
+// listMode 0: stage every cell ; 2: clean-up launch - a small grid that stages the cells without a list
 template <int MODE, int VDW>
 inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
                                 int maxBlocks, hipStream_t stream, PairRange R, PairLists L, int listMode)
@@ -722,10 +827,20 @@ inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const D
     if (R.n == 0) return;
     if (listMode == 2)
         hipLaunchKernelGGL((k_pair_tile<MODE, VDW, true>), dim3(pair_cleanup_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
-                           cnt, R.blockBase, L, listMode);
+                           cnt, R.blockBase, L);
     else
-        hipLaunchKernelGGL((k_pair_tile<MODE, VDW, false>), dim3(pair_range_grid(R.n)), dim3(kWave), listMode == 1 ? sizeof(uint32_t) * kTileCap : 0, stream, P, S, pots, A,
-                           cellStart, R.first, R.n, partials, maxBlocks, cnt, R.blockBase, L, listMode);
+        hipLaunchKernelGGL((k_pair_tile<MODE, VDW, false>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
+                           cnt, R.blockBase, L);
+}
+
+// the step that rebuilds the cells: candidates and pair lists of every cell (no forces; k_pair_list follows)
+inline void launch_build_lists(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, hipStream_t stream,
+                               PairRange R, PairLists L)
+{
+    pair_range_default(P, R);
+    if (R.n == 0) return;
+    hipLaunchKernelGGL((k_pair_tile<1, 1, false, true>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, (double*)nullptr, 0, cnt,
+                       0, L);
 }
 
 // dispatch on the potential set.  P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs; 5 = a mix of
