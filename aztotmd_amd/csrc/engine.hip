@@ -397,6 +397,7 @@ void Engine::allocate()
                     HIP_CHECK(hipStreamSynchronize(stream_));
                 }
                 HIP_CHECK(hipMemsetAsync(dCandList_, 0, sizeof(uint32_t) * nc * kTileCap, stream_));      // every entry is an atom index at all times
+                HIP_CHECK(hipMemsetAsync(dPairList_, 0, sizeof(uint16_t) * nc * kListStride16, stream_));   // every entry is a tile offset at all times (k_pair_list reads ahead)
                 HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(int32_t) * 4, stream_));
                 listsOn_ = true;
             }

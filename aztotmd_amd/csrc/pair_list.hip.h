@@ -47,6 +47,8 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
 #pragma unroll
     for (int u = 0; u < kRounds - 1; u++) ent[u] = myList[u * kWave];
     uint4 w = pl[0];
+    uint4 w1 = pl[kWave];                                           // (the second chunk too: 16 iterations cover a liquid's cells, and a chunk asked for only
+                                                                    //  8 iterations ahead arrives late)
     const int cnt = L.laneCnt[(size_t)cell * kWave + lane];
     const int2 mx = ((const int2*)L.meta)[cell];                   // {list header, cell coordinates lx | cy << 10 | cz << 20}: one scalar load, no integer divisions
     int meta = mx.x;
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         fetch(nIter > 0 ? (w.x & 0xFFFFu) : 0u, xj, yj, zj, tj, radj);
         for (int c = 0; c < nChunks; c++)
         {
-            uint4 wn = {0u, 0u, 0u, 0u};
-            if (c + 1 < nChunks) wn = pl[(c + 1) * kWave];
+            uint4 wn = w1;
+            if (c + 2 < nChunks) w1 = pl[(c + 2) * kWave];
             const uint32_t ww[5] = {w.x, w.y, w.z, w.w, wn.x};
 #pragma unroll
             for (int u = 0; u < 8; u++)
@@ -201,7 +203,10 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         }
         eV = acc.eV; eC = acc.eC; dropped = acc.dropped;
     }
-    eV = wave_sum(eV); eC = wave_sum(eC); dropped = wave_sum(dropped);
+    // (the reductions are ~14 vector instructions each: skipped where the sum is known to be zero)
+    eV = wave_sum(eV);
+    if (MODE != 1 && MODE != 4) eC = wave_sum(eC);
+    if (__any(dropped != 0.0)) dropped = wave_sum(dropped);
     if (lane == 0)
     {
         const size_t pb = (size_t)blockBase + blockIdx.x;

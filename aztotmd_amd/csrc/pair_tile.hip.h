@@ -354,7 +354,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
 // rc + 2 slack, then every atom's hits are dealt round-robin to the lanes that serve it.  Geometry only - independent of the potential set.
 template <int LG>
 __device__ __forceinline__ void deal_hits(const double* tx, const double* ty, const double* tz, const float* tw, uint4* tlist, int T, int slice, double xi, double yi,
-                                          double zi, float filtB, double r2List, int& nMine, int& overflow)
+                                          double zi, float filtB, double r2List, int kSelf, int& nMine, int& overflow)
 {
     constexpr int NS = kWave >> LG;
     constexpr int NR = (LG == 4) ? 1 : (LG == 5 ? 2 : 4);         // rounds of 96 candidates per lane that cover a full tile (320 / NS per lane)
@@ -369,6 +369,14 @@ __device__ __forceinline__ void deal_hits(const double* tx, const double* ty, co
         uint32_t m[4] = {0u, 0u, 0u, 0u};
         if (r * 96 < iters) tile_filter<LG, kTileLds, 3>(tx, ty, tz, tw, r * 96, iters, slice, xi, yi, zi, filtB, r2List, m);
         mm[3 * r] = m[0]; mm[3 * r + 1] = m[1]; mm[3 * r + 2] = m[2];
+    }
+    // the atom itself is a candidate of its own tile (kSelf, always a hit): not a partner - one entry less per atom
+    if (kSelf >= 0 && (kSelf & (NS - 1)) == slice)
+    {
+        const int c = kSelf >> (6 - LG);                       // its number among this lane's candidates
+#pragma unroll
+        for (int w = 0; w < 3 * NR; w++)
+            if ((c >> 5) == w) mm[w] &= ~(0x80000000u >> (c & 31));
     }
     // phase B: the tile is no longer needed - the list is assembled in its place.  Entries nobody writes read as offset 0 (k_pair_list reads one
     // candidate ahead of the one it evaluates)
@@ -648,8 +656,8 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                     int e = 0;
                     while (e < nEnt)
                     {
-                        // up to four entries at a time, as many as are sure to fit: the tile must have room for all their atoms (counted before pruning - an
-                        // exact count per run, taken after the loads, cost 60-100 us on the 1 M-atom box: it chains the runs of a group one behind the other)
+                        // up to four entries at a time, as many as are sure to fit: the tile must have room for all their atoms, counted before pruning (an
+                        // exact count per run, taken after the loads, chains the runs of a group one behind the other: 60-100 us on the 1 M-atom box if done always)
                         const int le = min(e + (lane & 3), nEnt - 1);
                         const int vj = entJ[le], vn = entN[le], vc = entC[le];
                         int g = 0;
@@ -662,7 +670,44 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                                 if (g == u && e + u < nEnt && nu <= room) { g = u + 1; room -= nu; }
                             }
                         }
-                        if (g == 0) { process(); flushed = true; continue; }   // tile full: run the passes on what is there, then go on filling
+                        if (g == 0)
+                        {   // The next run is not sure to fit by its atom count: stage it alone and look at what the pruning really keeps of it (rare: the last
+                            // runs of a crowded tile).  Only if that does not fit either is the tile full: run the passes on what is there, then go on filling
+                            const int j = __builtin_amdgcn_readlane(vj, 0) + lane, n0 = __builtin_amdgcn_readlane(vn, 0), code0 = __builtin_amdgcn_readlane(vc, 0);
+                            double xj = 0.0, yj = 0.0, zj = 0.0, rad0 = 0.0;
+                            int typ0 = 0;
+                            if (lane < n0)
+                            {
+                                xj = ld_f64(A.x, j); yj = ld_f64(A.y, j); zj = ld_f64(A.z, j);
+                                if (!kOneSpecies) typ0 = ld_i32(A.type, j);
+                                if ((MODE == 0 && P.use_radii) || MODE == 4) rad0 = ld_f64(A.rad, j);
+                            }
+                            if (code0 != 0x15)
+                            {
+                                const int c0 = code0 & 3, c1 = (code0 >> 2) & 3, c2 = (code0 >> 4) & 3;
+                                xj += c0 == 0 ? -P.L[0] : (c0 == 2 ? P.L[0] : 0.0);
+                                yj += c1 == 0 ? -P.L[1] : (c1 == 2 ? P.L[1] : 0.0);
+                                zj += c2 == 0 ? -P.L[2] : (c2 == 2 ? P.L[2] : 0.0);
+                            }
+                            xj -= cc0; yj -= cc1; zj -= cc2;
+                            const double bx = fmax(fabs(xj) - h0, 0.0), by = fmax(fabs(yj) - h1, 0.0), bz = fmax(fabs(zj) - h2, 0.0);
+                            const bool keep = (lane < n0) && (bx * bx + by * by + bz * bz) <= P.pruneR2;
+                            const unsigned long long mask = __ballot(keep);
+                            const int nk = __popcll(mask);
+                            if (T + nk > kTileCap) { process(); flushed = true; continue; }
+                            if (keep)
+                            {
+                                const int pp = T + lanes_below(mask);
+                                tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
+                                tw[pp] = -(float)(xj * xj + yj * yj + zj * zj);
+                                if (BUILD) tent[pp] = (uint32_t)j | ((uint32_t)code0 << 26);
+                                if (!kOneSpecies) ttyp[pp] = (uint8_t)typ0;
+                                if (MODE == 0 || MODE == 4) trad[pp] = rad0;
+                            }
+                            T += nk;
+                            e += 1;
+                            continue;
+                        }
                         double gx[4], gy[4], gz[4], grad[4];
                         int gtyp[4], gjn[4], gcode[4];
 #pragma unroll
@@ -734,11 +779,20 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                                                                                      : (float)(thrList - (xi * xi + yi * yi + zi * zi));
                     const double r2List = P.pruneR2 * (1.0 + 1e-13);
                     int nMine = 0, overflow = 0;
+                    // where the cell's own atoms sit in the tile (they are candidates too, unshifted): found by their list entries
+                    for (int q = lane; q < T; q += kWave)
+                    {
+                        const uint32_t en = tent[q];
+                        const int rel = (int)(en & 0x3FFFFFFu) - ib;
+                        if ((en >> 26) == 0x15u && rel >= 0 && rel < nthis) entJ[rel] = q;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int kSelf = validI ? entJ[il] : -1;
                     uint4* const tlist = (uint4*)txyz;             // the list is assembled where the tile was
                     static_assert(sizeof(double) * 3 * kTileLds >= sizeof(uint16_t) * kListStride16, "the list is assembled where the tile was");
-                    if (lg == 4) deal_hits<4>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, nMine, overflow);
-                    else if (lg == 5) deal_hits<5>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, nMine, overflow);
-                    else deal_hits<6>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, nMine, overflow);
+                    if (lg == 4) deal_hits<4>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, kSelf, nMine, overflow);
+                    else if (lg == 5) deal_hits<5>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, kSelf, nMine, overflow);
+                    else deal_hits<6>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, kSelf, nMine, overflow);
                     __builtin_amdgcn_wave_barrier();
                     const int ls = 6 - lg, ns = 1 << ls;                             // log2(slices), slices
                     nIter = wave_max_int((nMine + ns - 1) >> ls);

@@ -232,6 +232,7 @@ def main():
                                     "S40": "40 000 atoms, surk rc 6.0 + radii on 2.7 A cells, radiative thermostat 500 K"}.get(a.workload, a.workload),
                        "n_atoms": n_atoms, "n_cells": st["n_cells"], "decomposition": "single GPU" if world == 1 else "%d slabs along x" % world, "transport": transport, "rccl_ranks": rccl_ranks, "ranks_share_gpus": oversubscribed,
                        "pair_variant": a.pair_variant, "sort_interval": st.get("sort_interval"), "sort_violations": st.get("sort_violations"),
+                       "pair_lists": st.get("pair_lists"), "cells_without_list": st.get("cells_without_list"),
                        "kernel_timing": "second pass of the same %d steps with HIP events on the engine stream" % a.steps if profile else "off"},
             "matom_steps_per_s": n_atoms * a.steps / wall / 1e6,
             "ms_per_step_with_events": (wall_events / a.steps * 1e3) if wall_events else None,
@@ -244,7 +245,8 @@ def main():
             pair_name = max((k for k in kern if k.startswith("pair")), key=lambda k: kern[k]["avg_us"] * kern[k]["calls"], default=None)
             if pair_name:
                 t_pair = kern[pair_name]["avg_us"] * 1e-6
-                alg = PAIR_BYTES_PER_ATOM * n_atoms / world + PAIR_BYTES_PER_CELL * st["n_cells"] / world
+                n_rank = n_atoms / (a.emulate_ranks if a.emulate_ranks > 1 else world)       # atoms one rank's pair kernel serves
+                alg = PAIR_BYTES_PER_ATOM * n_rank + PAIR_BYTES_PER_CELL * st["n_cells"] / world
                 traffic = flop = None
                 rec = {}
                 tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -266,8 +268,10 @@ def main():
                                    "fp64_frac": (flop / t_pair / FP64_VECTOR_PEAK) if flop else None,
                                    "fp64_peak_tflops": FP64_VECTOR_PEAK / 1e12,
                                    "counters_from": rec.get("round"),
-                                   "note": "fp64 pair kernel is FP64-ALU bound (about 100 FLOP per compulsory byte); fp64_flop_per_launch = "
-                                           "(2 FMA + ADD + MUL + TRANS) x 64 + 512 MFMA_MOPS from the SQ_INSTS_VALU_*_F64 counters in profiles/"}
+                                   "note": "frac counts the COMPULSORY bytes (52 B/atom + 8 B/cell); traffic is what the kernel really moves - pair_list streams its "
+                                           "candidate and pair lists (about 3.3 KB per cell, recorded when the cells were rebuilt) once per step, which is what replaces "
+                                           "staging, filtering and mask handling; fp64_flop_per_launch = (2 FMA + ADD + MUL + TRANS) x 64 + 512 MFMA_MOPS from the "
+                                           "SQ_INSTS_VALU_*_F64 counters in profiles/"}
             # the streaming kernels: algorithmic bytes / launch time / HBM peak
             n_local = n_atoms / world
             stream = {}

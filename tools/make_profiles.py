@@ -56,7 +56,15 @@ if os.path.isdir(fp64_dir):
 tp = os.path.join(P, "pmc_traffic.json")
 rec = json.load(open(tp)) if os.path.exists(tp) else {}
 for r in rows:
-    name = "pair_tile" if r["kernel"].startswith("k_pair_tile<") else ("pair_atom" if r["kernel"] == "k_pair_atom" else None)
+    k = r["kernel"]
+    # bench.py's names: k_pair_list -> pair_list ; k_pair_tile<MODE, VDW, CLEANUP, BUILD>: BUILD -> build_lists, CLEANUP -> pair_cleanup, else pair_tile
+    if k.startswith("k_pair_list<"):
+        name = "pair_list"
+    elif k.startswith("k_pair_tile<"):
+        a = [x.strip() for x in k[k.index("<") + 1:k.rindex(">")].split(",")]
+        name = "build_lists" if (len(a) > 3 and a[3] == "true") else ("pair_cleanup" if (len(a) > 2 and a[2] == "true") else "pair_tile")
+    else:
+        name = "pair_atom" if k == "k_pair_atom" else None
     if name:
         rec["%s:%s:%d" % (workload, name, ngpu)] = {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"], "fp64_flop_per_launch": flop.get(r["kernel"]), "round": tag, "kernel": r["kernel"],
                                                     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH doubled per MI355X_MICROARCH.md"}
