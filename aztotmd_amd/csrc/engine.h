@@ -153,10 +153,22 @@ private:
     std::vector<hipEvent_t> eventPool_;
     void drain_events();
 
-    // hipGraph replay of a pair of steps (ping-pong buffers)
-    hipGraph_t graph_[2] = {nullptr, nullptr};
-    hipGraphExec_t graphExec_[2] = {nullptr, nullptr};
+    // hipGraph replay of a cycle of steps.  Kernel arguments are baked in at capture time, so a graph is valid for the buffer state it was captured in
+    // (which AtomArrays is current, which coordinate arrays each of them holds: the sort ping-pongs the buffers, the fused next-step epilogue swaps
+    // coordinate arrays); it also remembers the state it leaves behind
+    struct BufState { int cur; double* xyz[2][3]; double* alt[2][3]; };
+    struct GraphSlot { BufState before, after; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    std::vector<GraphSlot> graphs_;
+    BufState buf_state() const;
+    void set_buf_state(const BufState& b);
     bool capturing_ = false;
+    // next-step fusion (pair_tile.hip.h NextStep): on plain NVE steps of a lazy run on one GPU the pair kernel's epilogue also does the next step's
+    // k_integrate1_bin<2>; the new positions go to a second set of coordinate arrays, swapped in after the launch
+    double* altXyz_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    bool fuseNextOk_ = false;       // this engine may fuse (decided once)
+    bool fuseNext_ = false;         // the pair kernel of the step being launched fuses
+    bool preIntegrated_ = false;    // the step being launched was opened by the previous step's pair kernel: no k_integrate1_bin
+    int stepsLeftInRun_ = 0;        // steps that follow the one being launched before the host looks / the cycle ends
 };
 
 void check_hip(hipError_t e, const char* what);

@@ -219,6 +219,24 @@ void Engine::construct()
         // instead of 63 + 76 MB per step) for no gain, so large systems fold it into the next step's streaming k_integrate1_bin.
         fuseEpilogue_ = plainNve && variant >= 2 && capacity_ <= kFuseKickMaxAtoms && !(opt_.reserved[0] & 256);   // debug bit 256: large-system path
         lazyKick_ = plainNve && !fuseEpilogue_;
+        // next-step fusion (NextStep, pair_tile.hip.h): one GPU, plain NVE (nothing happens between the forces and the next half-kick), a lazy run that walks
+        // pair lists; debug bit 131072 switches it off.  Small systems only, where a step is bound by launch latency (C2: 0.0230 -> 0.0199 ms/step): on 1 M
+        // atoms the 13-lane stores of the epilogue cost the pair kernel exactly what the streaming k_integrate1_bin<2> costs on its own (111 + 31 -> 140 us),
+        // debug bit 262144 forces it on there (measurements)
+        if (nranks_ == 1 && plainNve && listsOn_ && variant == 2 && !(opt_.reserved[0] & 131072) && (capacity_ <= kFuseKickMaxAtoms || (opt_.reserved[0] & 262144)))
+        {
+            fuseNextOk_ = true;
+            const size_t nd = sizeof(double) * (size_t)capacity_;
+            for (int b = 0; b < 2; b++)
+                for (int d = 0; d < 3; d++)
+                {
+                    void* p = nullptr;
+                    HIP_CHECK(hipMalloc(&p, std::max<size_t>(nd, 16)));
+                    allocs_.push_back(p);
+                    altXyz_[b][d] = (double*)p;
+                    HIP_CHECK(hipMemsetAsync(p, 0, nd, stream_));
+                }
+        }
     }
     if (nranks_ > 1 && !xch_)
     {   // options.reserved[1]: loopback measurement mode (see LoopbackExchanger)
@@ -233,11 +251,33 @@ Engine::~Engine() { release(); }
 
 void Engine::destroy_graphs()
 {
-    for (int g = 0; g < 2; g++)
+    for (GraphSlot& g : graphs_)
     {
-        if (graphExec_[g]) (void)hipGraphExecDestroy(graphExec_[g]);
-        if (graph_[g]) (void)hipGraphDestroy(graph_[g]);
-        graphExec_[g] = nullptr; graph_[g] = nullptr;
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    graphs_.clear();
+}
+
+Engine::BufState Engine::buf_state() const
+{
+    BufState b;
+    b.cur = cur_;
+    for (int k = 0; k < 2; k++)
+    {
+        b.xyz[k][0] = buf_[k].x; b.xyz[k][1] = buf_[k].y; b.xyz[k][2] = buf_[k].z;
+        for (int d = 0; d < 3; d++) b.alt[k][d] = altXyz_[k][d];
+    }
+    return b;
+}
+
+void Engine::set_buf_state(const BufState& b)
+{
+    cur_ = b.cur;
+    for (int k = 0; k < 2; k++)
+    {
+        buf_[k].x = b.xyz[k][0]; buf_[k].y = b.xyz[k][1]; buf_[k].z = b.xyz[k][2];
+        for (int d = 0; d < 3; d++) altXyz_[k][d] = b.alt[k][d];
     }
 }
 
@@ -683,8 +723,21 @@ void Engine::launch_pair()
                     HIP_CHECK(hipMemsetAsync(dNoList_ + 2, 0, sizeof(int32_t), stream_));     // cells without a list: counted anew
                     timed("build_lists", [&] { launch_build_lists(Q, S_, dPots_, cur(), dCounts_, dCellStart_, stream_, PairRange(), pl); });
                 }
-                timed("pair_list", [&] { splitBlocks_ = launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl); });
-                timed("pair_cleanup", [&] { splitBlocks_ += launch_pair_cleanup(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl); });
+                NextStep nx;
+                if (fuseNextOk_)
+                {
+                    nx.st = dStats_; nx.cnt = dCounts_; nx.R0 = ref_;
+                    if (fuseNext_) { nx.xn = altXyz_[cur_][0]; nx.yn = altXyz_[cur_][1]; nx.zn = altXyz_[cur_][2]; }
+                    else nx.pendingAfter = lazyKick_ ? 1 : -1;
+                }
+                timed("pair_list", [&] { splitBlocks_ = launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, nx); });
+                timed("pair_cleanup", [&] { splitBlocks_ += launch_pair_cleanup(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, nx); });
+                if (fuseNext_)
+                {   // the next step's positions are in the other set of coordinate arrays now
+                    AtomArrays& A = cur();
+                    std::swap(A.x, altXyz_[cur_][0]); std::swap(A.y, altXyz_[cur_][1]); std::swap(A.z, altXyz_[cur_][2]);
+                    preIntegrated_ = true;
+                }
             }
             else
                 timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, 0); });
@@ -718,8 +771,11 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
 {
     const int gridAtoms = div_up(capacity_, kBlock);
     const bool integrate_first = stepMode != 0;
+    P_.cycleStep = (stepMode == 2) ? sinceSort_ + 1 : 0;           // which step since the last rebuild (the slack-violation flag is indexed by it)
     if (stepMode == 2)
     {   // plain step of the lazy re-sort: integrate only; slots, cells and buffers stay as they are
+        if (preIntegrated_) preIntegrated_ = false;                 // the previous step's pair kernel has opened this step already (NextStep)
+        else
         timed("integrate1", [&] {
             hipLaunchKernelGGL(k_integrate1_bin<2>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,
                                dCellCount_, dPartials_, maxBlocks_, lay_, dMsg_[0], dMsg_[1], dStats_, ref_);
@@ -846,7 +902,15 @@ void Engine::launch_step_kernels()
     // plain NVE steps leave integrate2 to somebody else (decided once, in the constructor): small systems / slabs -> the tile
     // kernel's epilogue (fuseEpilogue_); large ones -> the next step's k_integrate1_bin (lazyKick_, see finish_steps)
     fuseNow_ = fuseEpilogue_;
-    sort_and_forces((lazyOn_ && sinceSort_ < lazyK_ - 1) ? 2 : 1);
+    const int stepMode = (lazyOn_ && sinceSort_ < lazyK_ - 1) ? 2 : 1;
+    {   // does this step's pair kernel also open the next step?  Only if there is one before the host looks or the cycle ends, if it is a plain step,
+        // and if this step walks the lists (k_pair_list and its clean-up launch carry the epilogue)
+        const int sinceAfter = (stepMode == 2) ? sinceSort_ + 1 : 0;
+        const bool nextPlain = lazyOn_ && sinceAfter < lazyK_ - 1;
+        const bool lists = listsOn_ && lazyOn_ && lazyK_ > 1 && pair_variant() == 2;
+        fuseNext_ = fuseNextOk_ && lists && nextPlain && stepsLeftInRun_ > 0;
+    }
+    sort_and_forces(stepMode);
     const bool fused = fuseNow_;                 // launch_pair drops the request if the tile kernel is not the one running
     fuseNow_ = false;
     ekinFromPair_ = fused;
@@ -934,20 +998,25 @@ void Engine::run_steps(int nsteps)
     const bool can_graph = opt_.use_graph && (nranks_ == 1 || slabGraph) && !profile_;
     if (can_graph && nsteps >= cycle)
     {
-        // one graph per starting buffer because kernel arguments are baked in at capture time; a graph starts with a step that sorts
+        // one graph per buffer state because kernel arguments are baked in at capture time; a graph starts with a step that sorts
         if (graphCycle_ != cycle) { destroy_graphs(); graphCycle_ = cycle; }
         while (nsteps - done >= cycle)
         {
-            const int g = cur_;
-            if (!graphExec_[g])
+            const BufState now = buf_state();
+            GraphSlot* slot = nullptr;
+            for (GraphSlot& g : graphs_)
+                if (g.before.cur == now.cur && g.before.xyz[0][0] == now.xyz[0][0] && g.before.xyz[1][0] == now.xyz[1][0]) { slot = &g; break; }
+            if (!slot)
             {
-                const int curBefore = cur_;
+                GraphSlot g;
+                g.before = now;
                 HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
                 capturing_ = true;
                 try
                 {
                     sinceSort_ = 1 << 30;
-                    for (int k = 0; k < cycle; k++) launch_step_kernels();
+                    preIntegrated_ = false;
+                    for (int k = 0; k < cycle; k++) { stepsLeftInRun_ = cycle - 1 - k; launch_step_kernels(); }
                 }
                 catch (...)
                 {   // leave neither the stream in capture mode nor the engine believing it is capturing
@@ -955,21 +1024,27 @@ void Engine::run_steps(int nsteps)
                     (void)hipStreamEndCapture(stream_, &broken);
                     if (broken) (void)hipGraphDestroy(broken);
                     capturing_ = false;
-                    cur_ = curBefore;
+                    preIntegrated_ = false;
+                    set_buf_state(now);
                     throw;
                 }
                 capturing_ = false;
-                HIP_CHECK(hipStreamEndCapture(stream_, &graph_[g]));
-                HIP_CHECK(hipGraphInstantiate(&graphExec_[g], graph_[g], nullptr, nullptr, 0));
-                cur_ = curBefore;                 // the capture itself executed nothing
+                HIP_CHECK(hipStreamEndCapture(stream_, &g.graph));
+                HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+                g.after = buf_state();
+                set_buf_state(now);               // the capture itself executed nothing
+                graphs_.push_back(g);
+                slot = &graphs_.back();
             }
-            HIP_CHECK(hipGraphLaunch(graphExec_[g], stream_));
+            HIP_CHECK(hipGraphLaunch(slot->exec, stream_));
             done += cycle;
-            if (K > 1) cur_ ^= 1;                 // one sort per cycle
+            set_buf_state(slot->after);           // one sort per cycle (K > 1) and the coordinate-array swaps of the fused steps
             sinceSort_ = 1 << 30;                 // the next cycle (or the eager remainder) starts with a sort
         }
     }
-    for (; done < nsteps; done++) launch_step_kernels();
+    preIntegrated_ = false;
+    for (; done < nsteps; done++) { stepsLeftInRun_ = nsteps - 1 - done; launch_step_kernels(); }
+    stepsLeftInRun_ = 0;
 }
 
 // the largest step any atom made since the last look sizes the next calls' sort interval: K steps of that length use at most half the slack

@@ -304,11 +304,19 @@ struct Counts
     int32_t nRecv;                  // atoms appended by k_unpack in the step in flight
     int32_t overflow;               // sticky: a fixed-capacity buffer was too small
     int32_t bondedMissing;          // sticky: a bond / angle partner was not resident on this rank (k_bonded)
-    int32_t lazyViolated;           // lazy re-sort: an atom has left the slack of its cell since the last sort (set by k_integrate1_bin on plain
-                                    // steps, cleared on sort steps): the pair kernels widen their stencil by one cell until the next sort
+    int32_t lazyViolated;           // lazy re-sort: 0, or the first step since the last rebuild (StepParams::cycleStep) whose positions have an atom outside the
+                                    // slack of its cell (set by whoever integrates - k_integrate1_bin on plain steps, or the pair kernel's epilogue one step
+                                    // ahead -, cleared on rebuild steps): from that step on the pair kernels widen their stencil by one cell until the next rebuild
     int32_t lazyViolatedEver;       // sticky copy for the host, which then shortens the sort interval
     unsigned long long maxStep2;    // bit pattern of the largest |v dt|^2 of any atom since the host last looked (non-negative doubles order like integers)
 };
+
+// has an atom left its cell's slack as of the step this launch belongs to?
+__device__ __forceinline__ bool slack_violated(const StepParams& P, const Counts* c)
+{
+    const int v = c->lazyViolated;
+    return v != 0 && v <= P.cycleStep;
+}
 
 // image index of a coordinate with exactly the case distinction of put_periodic / wrap_coord (box.cpp:243-252: x in [0, L] is image 0)
 __device__ __forceinline__ int image_of(double x, double L, double invL)
@@ -417,7 +425,11 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
             const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
             if (bits > __hip_atomic_load(&cnt->maxStep2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cnt->maxStep2, bits);
         }
-        if (!BIN && __syncthreads_or(violated) && threadIdx.x == 0) { cnt->lazyViolated = 1; cnt->lazyViolatedEver = 1; }
+        if (!BIN && __syncthreads_or(violated) && threadIdx.x == 0)
+        {   // (an earlier violation keeps its step; all writers of one launch write the same value)
+            if (cnt->lazyViolated == 0) cnt->lazyViolated = max(P.cycleStep, 1);
+            cnt->lazyViolatedEver = 1;
+        }
     }
     if (BIN && P.nranks > 1)
     {
@@ -674,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_atom(StepParams P, SpecTable S,
     __shared__ double scratch[kBlock / kWave];
     const int i = cnt->ownedBegin + blockIdx.x * kBlock + threadIdx.x;
     PairAcc acc = {0, 0, 0, 0, 0, 0};
-    if (P.nranks == 1 && cnt->lazyViolated)
+    if (P.nranks == 1 && slack_violated(P, cnt))
         for (int k = 0; k < 3; k++) { P.hw[k] += 1; P.nOff[k] = min(2 * P.hw[k] + 1, P.nc[k]); }     // an atom has left its cell's slack: reach one cell further
     if (i < cnt->ownedEnd)
     {

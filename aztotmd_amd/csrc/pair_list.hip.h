@@ -21,7 +21,8 @@ namespace aztot {
 template <int MODE, int VDW>
 __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
-                                                     double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase, PairLists L)
+                                                     double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase, PairLists L,
+                                                     NextStep N)
 {
     constexpr bool kOneSpecies = (MODE == 1 || MODE == 4);           // no species table, no type ids
     constexpr bool kRadii = (MODE == 0 || MODE == 4);
@@ -34,8 +35,10 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     const int per = (nCellsRun + 7) >> 3;
     const int cr = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware: each XCD owns a contiguous eighth of the cells
     double eV = 0.0, eC = 0.0, dropped = 0.0, eK = 0.0;
+    NextAcc nacc;
+    next_acc_clear(nacc);
     // after a slack violation (one GPU) the clean-up launch stages every cell with the wider stencil: stand down
-    const bool violated = P.nranks == 1 && counts->lazyViolated;
+    const bool violated = P.nranks == 1 && slack_violated(P, counts);
     // everything that depends on the cell number only is requested at once, before anything is known about the cell (the loads stay inside the
     // arrays whatever they return): list header, the first four groups of candidate entries, the lane's first list chunk and entry count.  A wave's
     // life is then two memory round trips (these, then the coordinates) and the loop
@@ -87,6 +90,10 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         //  wait for each of them in turn)
         const int myl = validI ? myi : ib;
         const double xr = A.x[myl], yr = A.y[myl], zr = A.z[myl];
+        // NextStep: what the epilogue will need is asked for now - loaded there, at the end of the wave's life, it cost a memory round trip per wave (+30 us)
+        double v0x = 0.0, v0y = 0.0, v0z = 0.0, r0x = 0.0, r0y = 0.0, r0z = 0.0;
+        if (P.fuseKick || N.xn) { v0x = A.vx[myl]; v0y = A.vy[myl]; v0z = A.vz[myl]; }
+        if (N.xn) { r0x = N.R0.x[myl]; r0y = N.R0.y[myl]; r0z = N.R0.z[myl]; }
         double radi = 0.0;
         int ti = 0;
         if (!kOneSpecies) ti = A.type[myl];
@@ -193,12 +200,14 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
             const double fyi = -q * P.E[1] + acc.fy;
             const double fzi = -q * P.E[2] + acc.fz;
             A.fx[myi] = fxi; A.fy[myi] = fyi; A.fz[myi] = fzi;
-            if (P.fuseKick)
-            {   // second half-kick + kinetic energy of integrate2 (integrators.cpp:486-531 ; verlet_2stage cuMDfunc.cu:521-600)
+            if (P.fuseKick || N.xn)
+            {   // second half-kick + kinetic energy of integrate2 (integrators.cpp:486-531 ; verlet_2stage cuMDfunc.cu:521-600); with NextStep also the
+                // next step's k_integrate1_bin<2>
                 const double rM = S.rMhdt[ti], m = S.mass[ti];
-                const double vx = A.vx[myi] + rM * fxi, vy = A.vy[myi] + rM * fyi, vz = A.vz[myi] + rM * fzi;
+                double vx = v0x + rM * fxi, vy = v0y + rM * fyi, vz = v0z + rM * fzi;
+                if (P.fuseKick) eK += (vx * vx + vy * vy + vz * vz) * m;
+                if (N.xn) next_step_atom(P, S, N, myi, ti, xr, yr, zr, fxi, fyi, fzi, vx, vy, vz, r0x, r0y, r0z, nacc);
                 A.vx[myi] = vx; A.vy[myi] = vy; A.vz[myi] = vz;
-                eK += (vx * vx + vy * vy + vz * vz) * m;
             }
         }
         eV = acc.eV; eC = acc.eC; dropped = acc.dropped;
@@ -219,35 +228,42 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         eK = wave_sum(eK);
         if (lane == 0) partials[(size_t)PS_EKIN * maxBlocks + blockBase + blockIdx.x] = 0.5 * eK;
     }
+    if (N.xn)
+    {
+        next_step_finish(P, N, nacc, partials, maxBlocks, (size_t)blockBase + blockIdx.x);
+        // the step counter of the step being opened (main.cpp:92), and: its second half-kick is NOT owed to the next k_integrate1_bin
+        if (blockIdx.x == 0 && lane == 0) { N.st->step += 1; N.st->pendingKick = 0; }
+    }
+    else if (N.pendingAfter >= 0 && blockIdx.x == 0 && lane == 0) N.st->pendingKick = N.pendingAfter;
 }
 
 template <int MODE, int VDW>
 inline void launch_pair_list_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
-                                int maxBlocks, hipStream_t stream, PairRange R, PairLists L)
+                                int maxBlocks, hipStream_t stream, PairRange R, PairLists L, NextStep N)
 {
     hipLaunchKernelGGL((k_pair_list<MODE, VDW>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt,
-                       R.blockBase, L);
+                       R.blockBase, L, N);
 }
 
 // a plain step: the list kernel for every cell (launch_pair_list), then the clean-up launch of the staging kernel for the cells that keep no list
 // (launch_pair_cleanup; it books into the partial-sum slots behind the list kernel's).  Each returns the number of partial-sum slots it uses.
 inline int launch_pair_list(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
-                            double* partials, int maxBlocks, hipStream_t stream, PairRange R, PairLists L)
+                            double* partials, int maxBlocks, hipStream_t stream, PairRange R, PairLists L, NextStep N = NextStep())
 {
     pair_range_default(P, R);
     if (R.n == 0) return 0;
-    auto list = [&]() { AZTOT_PAIR_DISPATCH(launch_pair_list_as, P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L); };
+    auto list = [&]() { AZTOT_PAIR_DISPATCH(launch_pair_list_as, P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, N); };
     list();
     return pair_range_grid(R.n);
 }
 
 inline int launch_pair_cleanup(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
-                               double* partials, int maxBlocks, hipStream_t stream, PairRange R, PairLists L)
+                               double* partials, int maxBlocks, hipStream_t stream, PairRange R, PairLists L, NextStep N = NextStep())
 {
     pair_range_default(P, R);
     if (R.n == 0) return 0;
     R.blockBase += pair_range_grid(R.n);
-    launch_pair_tile(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, 2);
+    launch_pair_tile(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, 2, N);
     return pair_cleanup_grid(R.n);
 }
 

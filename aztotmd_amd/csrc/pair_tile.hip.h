@@ -438,6 +438,83 @@ __device__ __forceinline__ int wave_max_int(int v)
     return v;
 }
 
+// The next step's first half, fused into the epilogue of this step's pair kernel (one GPU, plain NVE steps of a lazy run that walks pair lists): the lane that
+// has just written an atom's force also completes this step's second half-kick, applies the next step's first one and drifts the atom - everything
+// k_integrate1_bin<2> would do in a launch of its own (31 us on the 1 M-atom box), operation for operation: deferred kick, kick, drift, wall-crossing
+// counters, longest step, displacement against the slack.  The new position goes into a SECOND set of coordinate arrays: other waves still read this step's
+// positions; the engine swaps the two sets after the launch.
+struct NextStep
+{
+    double *xn = nullptr, *yn = nullptr, *zn = nullptr;     // where the next step's positions go (nullptr: no fusion in this launch)
+    RefPos R0{};                                             // positions at the last rebuild
+    DevStats* st = nullptr;
+    Counts* cnt = nullptr;
+    int pendingAfter = -1;                                   // launches that do NOT fuse, in an engine that sometimes does: what k_pair_list leaves in DevStats::pendingKick
+                                                             // (1: this step's second half-kick is owed to the next k_integrate1_bin / k_integrate2 ; -1: hands off)
+};
+
+// per-lane part; the wave-level bookkeeping follows in next_step_finish.  (Scalars on purpose: as two arrays of six the wall sums ended up in scratch
+// memory, which cost every launch of the kernel 40 %.)
+struct NextAcc { double mx, my, mz, stepLen2; int cx, cy, cz, violated; };      // wall crossed along x / y / z: -1 lower wall, +1 upper wall; m v of the crossing
+__device__ __forceinline__ void next_acc_clear(NextAcc& a) { a.mx = a.my = a.mz = 0.0; a.stepLen2 = 0.0; a.cx = a.cy = a.cz = 0; a.violated = 0; }
+
+// v holds the velocity with this step's second half-kick already applied (same operand order as k_integrate1_bin's deferred kick)
+__device__ __forceinline__ void next_step_atom(const StepParams& P, const SpecTable& S, const NextStep& N, int i, int t, double x, double y, double z,
+                                               double fx, double fy, double fz, double& vx, double& vy, double& vz, double rx, double ry, double rz, NextAcc& a)
+{
+    const double rM = S.rMhdt[t], m = S.mass[t];
+    vx += rM * fx; vy += rM * fy; vz += rM * fz;                   // the next step's first half-kick (integrators.cpp:293-330 ; verlet_1stage cuMDfunc.cu:333-470)
+    const int ix0 = image_of(x, P.L[0], P.invL[0]), iy0 = image_of(y, P.L[1], P.invL[1]), iz0 = image_of(z, P.L[2], P.invL[2]);
+    double dx = 0.0, dy = 0.0, dz = 0.0;
+    if (!S.frozen[t]) { dx = vx * P.dt; dy = vy * P.dt; dz = vz * P.dt; x += dx; y += dy; z += dz; }
+    a.stepLen2 = dx * dx + dy * dy + dz * dz;
+    int c;
+    c = image_of(x, P.L[0], P.invL[0]) - ix0;
+    if (c < 0) { a.mx = m * (-vx); a.cx = -1; } else if (c > 0) { a.mx = m * vx; a.cx = 1; }
+    c = image_of(y, P.L[1], P.invL[1]) - iy0;
+    if (c < 0) { a.my = m * (-vy); a.cy = -1; } else if (c > 0) { a.my = m * vy; a.cy = 1; }
+    c = image_of(z, P.L[2], P.invL[2]) - iz0;
+    if (c < 0) { a.mz = m * (-vz); a.cz = -1; } else if (c > 0) { a.mz = m * vz; a.cz = 1; }
+    const double ex = x - rx, ey = y - ry, ez = z - rz;             // (rx, ry, rz): where the atom was when the cells were rebuilt
+    if (ex * ex + ey * ey + ez * ez > P.lazySlack2) a.violated = 1;
+    // per-species crossing counters (specAcBoxNeg / specAcBoxPos of put_periodic, cuMDfunc.cu:35-106): crossings are rare, plain atomics
+    if (a.cx) atomicAdd(&N.st->specCross[t * 6 + (a.cx < 0 ? 0 : 1)], 1ULL);
+    if (a.cy) atomicAdd(&N.st->specCross[t * 6 + (a.cy < 0 ? 2 : 3)], 1ULL);
+    if (a.cz) atomicAdd(&N.st->specCross[t * 6 + (a.cz < 0 ? 4 : 5)], 1ULL);
+    N.xn[i] = x; N.yn[i] = y; N.zn[i] = z;
+}
+
+__device__ __forceinline__ void next_wall_sum(double m, int c, int want, int slot, double* __restrict__ partials, int maxBlocks, size_t pb)
+{
+    const double s = wave_sum(c == want ? m : 0.0), b = wave_sum(c == want ? 1.0 : 0.0);
+    if ((threadIdx.x & (kWave - 1)) == 0 && b != 0.0) { partials[(size_t)(PS_MOM_XN + slot) * maxBlocks + pb] += s; partials[(size_t)(PS_CNT_XN + slot) * maxBlocks + pb] += b; }
+}
+
+// once per wave, all lanes: longest step, violation flag (for the NEXT step: cycleStep + 1), wall momenta / crossings into this workgroup's partial slots
+__device__ __forceinline__ void next_step_finish(const StepParams& P, const NextStep& N, NextAcc& a, double* __restrict__ partials, int maxBlocks, size_t pb)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    double mx = a.stepLen2;
+#pragma unroll
+    for (int o = kWave >> 1; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, kWave));
+    if (lane == 0)
+    {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
+        if (bits > __hip_atomic_load(&N.cnt->maxStep2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&N.cnt->maxStep2, bits);
+    }
+    if (__any(a.violated) && lane == 0)
+    {
+        if (N.cnt->lazyViolated == 0) N.cnt->lazyViolated = P.cycleStep + 1;
+        N.cnt->lazyViolatedEver = 1;
+    }
+    if (__any((a.cx | a.cy | a.cz) != 0))
+    {   // slots in the order Xn, Xp, Yn, Yp, Zn, Zp (PartialSlot)
+        next_wall_sum(a.mx, a.cx, -1, 0, partials, maxBlocks, pb); next_wall_sum(a.mx, a.cx, 1, 1, partials, maxBlocks, pb);
+        next_wall_sum(a.my, a.cy, -1, 2, partials, maxBlocks, pb); next_wall_sum(a.my, a.cy, 1, 3, partials, maxBlocks, pb);
+        next_wall_sum(a.mz, a.cz, -1, 4, partials, maxBlocks, pb); next_wall_sum(a.mz, a.cz, 1, 5, partials, maxBlocks, pb);
+    }
+}
+
 template <int MODE, int VDW, bool CLEANUP, bool BUILD = false>
                       // MODE 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;
                       // 3: as 2 with the real-space term of the Ewald sum ; 4: one species, surk with thermostat radii (case study 2).
@@ -447,7 +524,7 @@ template <int MODE, int VDW, bool CLEANUP, bool BUILD = false>
 __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase,
-                                                     PairLists L)
+                                                     PairLists L, NextStep N)
 {
     constexpr bool REC = BUILD;
     constexpr bool onlyUnlisted = CLEANUP;           // (a template parameter: with the strided loop of the clean-up launch in it the full launch lost 7 %)
@@ -456,7 +533,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
     __shared__ uint32_t tent[BUILD ? kTileCap : 1];
     // lazy re-sort (Engine::step): an atom has left the slack of the cell it was sorted into - until the next sort the stencil reaches one cell
     // further (rare; Engine::lazy_allowed guarantees that the wider stencil still sees every cell through one image only)
-    const bool widened = P.lazySlack2 > 0.0 && P.nranks == 1 && counts->lazyViolated;     // (a slab rank has no ghost layers to widen into: Engine reports the violation)
+    const bool widened = P.lazySlack2 > 0.0 && P.nranks == 1 && slack_violated(P, counts);     // (a slab rank has no ghost layers to widen into: Engine reports the violation)
     if (widened)
     {   // nothing is known about how far the atoms have strayed beyond the slack (less than a cell, the host halves the interval at once): no pruning
         for (int k = 0; k < 3; k++) { P.hw[k] += 1; P.nOff[k] = 2 * P.hw[k] + 1; }
@@ -476,6 +553,8 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
     const int lane = threadIdx.x;
     PairAcc acc = {0, 0, 0, 0, 0, 0};
     double eV = 0.0, eC = 0.0, dropped = 0.0, eK = 0.0;
+    NextAcc nacc;
+    next_acc_clear(nacc);
     const DevPot lj = pots[0];
     if (MODE == 2 || MODE == 3)
     {
@@ -830,13 +909,14 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                 const double fyi = -q * P.E[1] + acc.fy;
                 const double fzi = -q * P.E[2] + acc.fz;
                 A.fx[myi] = fxi; A.fy[myi] = fyi; A.fz[myi] = fzi;
-                if (P.fuseKick)
+                if (P.fuseKick || (CLEANUP && N.xn))
                 {   // second half-kick + kinetic energy of integrate2 (integrators.cpp:486-531 ; verlet_2stage cuMDfunc.cu:521-600),
                     // fused here on plain NVE steps: the force is still in registers
                     const double rM = S.rMhdt[ti], m = S.mass[ti];
-                    const double vx = A.vx[myi] + rM * fxi, vy = A.vy[myi] + rM * fyi, vz = A.vz[myi] + rM * fzi;
+                    double vx = A.vx[myi] + rM * fxi, vy = A.vy[myi] + rM * fyi, vz = A.vz[myi] + rM * fzi;
+                    if (P.fuseKick) eK += (vx * vx + vy * vy + vz * vz) * m;
+                    if (CLEANUP && N.xn) next_step_atom(P, S, N, myi, ti, A.x[myi], A.y[myi], A.z[myi], fxi, fyi, fzi, vx, vy, vz, N.R0.x[myi], N.R0.y[myi], N.R0.z[myi], nacc);      // (NextStep)
                     A.vx[myi] = vx; A.vy[myi] = vy; A.vz[myi] = vz;
-                    eK += (vx * vx + vy * vy + vz * vz) * m;
                 }
             }
             eV += acc.eV; eC += acc.eC; dropped += acc.dropped;
@@ -858,6 +938,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
         eK = wave_sum(eK);
         if (lane == 0) partials[(size_t)PS_EKIN * maxBlocks + blockBase + blockIdx.x] = 0.5 * eK;
     }
+    if (CLEANUP && N.xn) next_step_finish(P, N, nacc, partials, maxBlocks, (size_t)blockBase + blockIdx.x);
 }
 
 // a run of cells for one launch: first cell, number of cells, first partial-sum slot; n < 0: all the cells this rank owns
@@ -875,16 +956,16 @@ inline void pair_range_default(const StepParams& P, PairRange& R)
 // listMode 0: stage every cell ; 2: clean-up launch - a small grid that stages the cells without a list
 template <int MODE, int VDW>
 inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
-                                int maxBlocks, hipStream_t stream, PairRange R, PairLists L, int listMode)
+                                int maxBlocks, hipStream_t stream, PairRange R, PairLists L, int listMode, NextStep N)
 {
     pair_range_default(P, R);
     if (R.n == 0) return;
     if (listMode == 2)
         hipLaunchKernelGGL((k_pair_tile<MODE, VDW, true>), dim3(pair_cleanup_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
-                           cnt, R.blockBase, L);
+                           cnt, R.blockBase, L, N);
     else
         hipLaunchKernelGGL((k_pair_tile<MODE, VDW, false>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
-                           cnt, R.blockBase, L);
+                           cnt, R.blockBase, L, NextStep());
 }
 
 // the step that rebuilds the cells: candidates and pair lists of every cell (no forces; k_pair_list follows)
@@ -894,7 +975,7 @@ inline void launch_build_lists(const StepParams& P, const SpecTable& S, const De
     pair_range_default(P, R);
     if (R.n == 0) return;
     hipLaunchKernelGGL((k_pair_tile<1, 1, false, true>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, (double*)nullptr, 0, cnt,
-                       0, L);
+                       0, L, NextStep());
 }
 
 // dispatch on the potential set.  P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs; 5 = a mix of
@@ -919,10 +1000,11 @@ inline void launch_build_lists(const StepParams& P, const SpecTable& S, const De
     } while (0)
 
 inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
-                             double* partials, int maxBlocks, hipStream_t stream, PairRange R = PairRange(), PairLists L = PairLists(), int listMode = 0)
+                             double* partials, int maxBlocks, hipStream_t stream, PairRange R = PairRange(), PairLists L = PairLists(), int listMode = 0,
+                             NextStep N = NextStep())
 {
     if (!L.cand) listMode = 0;
-    AZTOT_PAIR_DISPATCH(launch_pair_tile_as, P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, listMode);
+    AZTOT_PAIR_DISPATCH(launch_pair_tile_as, P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, listMode, N);
 }
 
 }  // namespace aztot

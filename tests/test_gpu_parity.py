@@ -572,6 +572,49 @@ def test_pair_lists_between_two_rebuilds(kind):
     assert abs(sta["engTot"] - sto["engTot"]) <= 1e-10 * abs(sto["engTot"])
 
 
+@pytest.mark.parametrize("kind", ["lj", "lj_fennell", "part_unlisted", "hot"])
+def test_next_step_fused_into_the_pair_kernel(kind):
+    """On plain NVE steps of a lazy run that walks pair lists the pair kernel's epilogue also opens the next step (deferred second half-kick, first half-kick,
+    drift, wall counters, displacement check: everything k_integrate1_bin<2> does), writing the new positions to a second set of coordinate arrays.  Same
+    operations in the same order: positions, velocities and forces must be BIT-IDENTICAL to a run with the fusion switched off (debug bit 131072), whatever
+    the pattern of calls (graph replay of whole cycles, eager remainders, single steps); wall counters equal, wall momenta to summation order.  'hot': a
+    9 000 K gas held at a 32-step interval (debug bit 8192) - atoms leave the slack, the violation is flagged one step ahead by the epilogue and the
+    clean-up launch (which carries the same epilogue) takes over."""
+    kw = {}
+    if kind in ("lj", "part_unlisted"):
+        case = inputs.lj_case((8, 8, 8), a=5.6, seed=41, rc=7.5, cell_list=7.9, vel_T=300.0)
+        if kind == "part_unlisted":
+            kw = dict(debug=65536)
+    elif kind == "lj_fennell":
+        case = inputs.lj_case((8, 8, 8), a=5.6, seed=42, rc=7.5, cell_list=7.9, vel_T=300.0, charges=(0.3, -0.3), elec="fenn", r_real=7.5, alpha=0.3)
+    else:
+        case = inputs.lj_case((7, 7, 7), a=5.4, seed=23, rc=6.5, cell_list=6.9, vel_T=9000.0)
+        case["dt"] = 0.002
+        kw = dict(sort_every=32, debug=8192)
+    a = engine(case, pair_variant=2, **kw)
+    kb = dict(kw)
+    kb["debug"] = kb.get("debug", 0) | 131072
+    b = engine(case, pair_variant=2, **kb)
+    o = oracle.Oracle(case)
+    o.forces(1)
+    for n in (10, 1, 37, 2, 33, 64, 5):
+        a.step(n); b.step(n); o.step(n)
+        sa, sb = a.state(), b.state()
+        for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+            assert np.array_equal(sa[k], sb[k]), (n, k, rel_err(sa[k], sb[k]))
+    sta, stb, so, sto = a.stats(), b.stats(), o.state(), o.stats()
+    assert sta["pair_lists"] == 1 and sta["sort_interval"] > 1
+    if kind == "hot":
+        assert sta["sort_violations"] > 0
+    assert sta["negCross"] + sta["posCross"] == stb["negCross"] + stb["posCross"] == [sto["cross"][k] for k in (0, 2, 4, 1, 3, 5)]
+    assert np.array_equal(a.species_crossings(), b.species_crossings())
+    assert rel_err(sta["negMom"] + sta["posMom"], stb["negMom"] + stb["posMom"]) < 1e-10
+    for k in ("engVdW", "engCoul", "engKin", "engTot"):
+        assert abs(sta[k] - stb[k]) <= 1e-12 * max(abs(stb[k]), 1e-3), (k, sta[k], stb[k])
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(sa[k], so[k]) < 1e-8, (k, rel_err(sa[k], so[k]))
+
+
 def test_tile_and_atom_kernels_agree_bitwise_on_energy_scale():
     case = inputs.config("F3")
     a, b = engine(case, pair_variant=1), engine(case, pair_variant=2)
