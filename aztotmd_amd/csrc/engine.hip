@@ -219,11 +219,12 @@ void Engine::construct()
         // instead of 63 + 76 MB per step) for no gain, so large systems fold it into the next step's streaming k_integrate1_bin.
         fuseEpilogue_ = plainNve && variant >= 2 && capacity_ <= kFuseKickMaxAtoms && !(opt_.reserved[0] & 256);   // debug bit 256: large-system path
         lazyKick_ = plainNve && !fuseEpilogue_;
-        // next-step fusion (NextStep, pair_tile.hip.h): one GPU, plain NVE (nothing happens between the forces and the next half-kick), a lazy run that walks
-        // pair lists; debug bit 131072 switches it off.  Small systems only, where a step is bound by launch latency (C2: 0.0230 -> 0.0199 ms/step): on 1 M
-        // atoms the 13-lane stores of the epilogue cost the pair kernel exactly what the streaming k_integrate1_bin<2> costs on its own (111 + 31 -> 140 us),
-        // debug bit 262144 forces it on there (measurements)
-        if (nranks_ == 1 && plainNve && listsOn_ && variant == 2 && !(opt_.reserved[0] & 131072) && (capacity_ <= kFuseKickMaxAtoms || (opt_.reserved[0] & 262144)))
+        // next-step fusion (NextStep, pair_tile.hip.h): plain NVE (nothing happens between the forces and the next half-kick; on slab ranks the coordinate
+        // exchange of the next step simply follows the pair kernel that produced the coordinates), a lazy run that walks
+        // pair lists; debug bit 131072 switches it off.  Up to ~500 000 atoms per GPU, where a step is bound by launch latency (measured: 40 000 atoms 0.0230 ->
+        // 0.0199 ms/step; emulated slab ranks of 143 000 / 250 000 / 333 000 atoms -9 % / -5 % / -4 %): on 1 M atoms the 13-lane stores of the epilogue cost
+        // the pair kernel exactly what the streaming k_integrate1_bin<2> costs on its own (111 + 31 -> 140 us); debug bit 262144 forces it on there
+        if (plainNve && listsOn_ && variant == 2 && !(opt_.reserved[0] & 131072) && (capacity_ <= 2 * kFuseKickMaxAtoms || (opt_.reserved[0] & 262144)))
         {
             fuseNextOk_ = true;
             const size_t nd = sizeof(double) * (size_t)capacity_;
