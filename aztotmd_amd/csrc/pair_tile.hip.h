@@ -14,7 +14,9 @@
 //   * every atom's force is the sum over ALL its neighbours (no Newton-3 halving): written once, no atomics,
 //     bit-reproducible; each pair visit books half of the pair energy;
 //   * workgroup -> cell mapping keeps each XCD on a contiguous eighth of the cell list (private L2 per XCD).
-// No MFMA: the work is distance tests and scalar-potential evaluations, not a contraction.
+// One matrix instruction: the distance filter of pass 1 (v_mfma_f32_16x16x4_f32 as a 256-wide comparator, tile_filter); the potential is vector fp64.
+// Three roles (template parameters of k_pair_tile): the force kernel of runs that rebuild their cells every step; the list-building launch of the lazy
+// re-sort (BUILD: no forces - candidates and per-atom pair lists for k_pair_list, pair_list.hip.h); the clean-up launch behind k_pair_list (CLEANUP).
 #pragma once
 #include "kernels.hip.h"
 
@@ -223,7 +225,7 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
 
 // Pass 1 of one round (NW words of 32 candidates per lane, starting at per-lane candidate rb): distance tests only; the hits come back as per-lane bit
 // masks m[0..NW-1], candidate number b of a word at bit 31 - b.  LG = log2(atom slots), NS = 64 >> LG lanes (slices) per atom; STRIDE: distance (in
-// entries) between the x, y and z arrays of the tile.  Shared by the force kernels (threshold rc^2) and by k_build_lists (threshold (rc + 2 slack)^2).
+// entries) between the x, y and z arrays of the tile.  Shared by the force kernels (threshold rc^2) and by the list-building launch (deal_hits, threshold (rc + 2 slack)^2).
 template <int LG, int STRIDE, int NW>
 __device__ __forceinline__ void tile_filter(const double* tx, const double* ty, const double* tz, const float* tw, int rb, int iters, int slice,
                                             double xi, double yi, double zi, float filtB, double r2Filter, uint32_t (&m)[4])
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
         }
         const double filtThr = P.r2Max + 1.9073486328125e-06 * (4.0 * ext2 + P.r2Max);      // 2^-19
         // Lists (lazy re-sort): on the step that rebuilds the cells the staging below also records WHICH atoms it kept (index + image code, in tile
-        // order), and k_build_lists then records which of them every atom of the cell interacts with; until the next rebuild the atoms keep their slots
+        // order) and, in the BUILD launch, which of them every atom of the cell interacts with (deal_hits); until the next rebuild the atoms keep their slots
         // and nobody moves farther than the slack the pruning radius already allows for, so the plain steps run k_pair_list: no run table, no pruning,
         // no compaction, no distance filter.  Cells whose stencil needs more than one tile or that hold more than 64 atoms keep no list.
         uint32_t* const myList = L.cand + (size_t)cell * kTileCap;       // (only touched when recording)

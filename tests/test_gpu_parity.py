@@ -532,7 +532,7 @@ def test_lazy_resort_is_exact(mode, variant):
 
 @pytest.mark.parametrize("kind", ["lj", "lj_fennell", "buck", "elin", "part_unlisted", "dense_cells"])
 def test_pair_lists_between_two_rebuilds(kind):
-    """The steps between two rebuilds of the cell list walk the pair lists the rebuild recorded (k_build_lists -> k_pair_list) instead of staging and
+    """The steps between two rebuilds of the cell list walk the pair lists the rebuild recorded (k_pair_tile<BUILD> -> k_pair_list) instead of staging and
     filtering every cell again: same forces as the every-step schedule (summation order aside) and as the oracle.  'part_unlisted': debug bit 65536
     caps the lists at 14 iterations, so part of the cells keep no list and go through the clean-up launch of the staging kernel while the others
     walk their lists; 'dense_cells': cells of 3 rc hold ~108 atoms (> 64: no cell keeps a list, everything goes through the clean-up launch until the
