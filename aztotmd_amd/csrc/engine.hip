@@ -424,7 +424,7 @@ void Engine::allocate()
                 dListMeta_ = (int32_t*)alloc(sizeof(int32_t) * 2 * nc);
                 dPairList_ = (uint16_t*)alloc(sizeof(uint16_t) * nc * kListStride16);
                 dLaneCnt_ = (uint8_t*)alloc(nc * kWave);
-                dNoList_ = (int32_t*)alloc(sizeof(int32_t) * 4);
+                dNoList_ = (int32_t*)alloc(sizeof(int32_t) * 8);
                 {   // header: -1 = no list ; second word: the cell's coordinates in the local grid (k_pair_list decodes them with shifts)
                     if (P_.ncxLocal > 1023 || P_.nc[1] > 1023 || P_.nc[2] > 1023) throw std::runtime_error("more than 1023 cells along an axis");
                     std::vector<int32_t> mx(2 * nc);
@@ -439,7 +439,7 @@ void Engine::allocate()
                 }
                 HIP_CHECK(hipMemsetAsync(dCandList_, 0, sizeof(uint32_t) * nc * kTileCap, stream_));      // every entry is an atom index at all times
                 HIP_CHECK(hipMemsetAsync(dPairList_, 0, sizeof(uint16_t) * nc * kListStride16, stream_));   // every entry is a tile offset at all times (k_pair_list reads ahead)
-                HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(int32_t) * 4, stream_));
+                HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(int32_t) * 8, stream_));
                 listsOn_ = true;
             }
         }
@@ -1083,6 +1083,13 @@ void Engine::adapt_sort_interval()
         // 64 atoms) - then the plain steps go back to staging every cell
         int32_t nl[2] = {0, 0};
         HIP_CHECK(hipMemcpy(nl, dNoList_, sizeof(nl), hipMemcpyDeviceToHost));
+        if (opt_.reserved[0] & 2097152)
+        {   // measurement aid: mean list length / tile size / atoms per cell over the cells recorded since the last look
+            int32_t q[8];
+            HIP_CHECK(hipMemcpy(q, dNoList_, sizeof(q), hipMemcpyDeviceToHost));
+            if (q[1] > 0) std::fprintf(stderr, "aztot: per cell: %.2f list iterations, %.1f candidates, %.2f atoms\n", (double)q[3] / q[1], (double)q[4] / q[1], (double)q[5] / q[1]);
+            HIP_CHECK(hipMemset(dNoList_ + 3, 0, sizeof(int32_t) * 3));
+        }
         if (nl[1] > 0)
         {
             HIP_CHECK(hipMemset(dNoList_, 0, sizeof(nl)));          // ([2] stays: it describes the lists in force)

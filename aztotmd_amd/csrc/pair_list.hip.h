@@ -35,12 +35,12 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     const int per = (nCellsRun + 7) >> 3;
     const int cr = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware: each XCD owns a contiguous eighth of the cells
     double eV = 0.0, eC = 0.0, dropped = 0.0, eK = 0.0;
-    NextAcc nacc;
-    next_acc_clear(nacc);
+    NextAcc nacc;                                                    // (touched only in launches that fuse the next step: no initialisation on the others)
+    if (N.xn) next_acc_clear(nacc);
     // after a slack violation (one GPU) the clean-up launch stages every cell with the wider stencil: stand down
     const bool violated = P.nranks == 1 && slack_violated(P, counts);
     // everything that depends on the cell number only is requested at once, before anything is known about the cell (the loads stay inside the
-    // arrays whatever they return): list header, the first four groups of candidate entries, the lane's first list chunk and entry count.  A wave's
+    // arrays whatever they return): list header, the five groups of candidate entries, the lane's first two list chunks and entry count.  A wave's
     // life is then two memory round trips (these, then the coordinates) and the loop
     const int cell = firstCell + min(cr, nCellsRun - 1);
     const uint32_t* const myList = L.cand + (size_t)cell * kTileCap + lane;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     constexpr int kRounds = kTileCap / kWave;
     uint32_t ent[kRounds];
 #pragma unroll
-    for (int u = 0; u < kRounds - 1; u++) ent[u] = myList[u * kWave];
+    for (int u = 0; u < kRounds; u++) ent[u] = myList[u * kWave];
     uint4 w = pl[0];
     uint4 w1 = pl[kWave];                                           // (the second chunk too: 16 iterations cover a liquid's cells, and a chunk asked for only
                                                                     //  8 iterations ahead arrives late)
@@ -91,52 +91,48 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         const int myl = validI ? myi : ib;
         const double xr = A.x[myl], yr = A.y[myl], zr = A.z[myl];
         // NextStep: what the epilogue will need is asked for now - loaded there, at the end of the wave's life, it cost a memory round trip per wave (+30 us)
-        double v0x = 0.0, v0y = 0.0, v0z = 0.0, r0x = 0.0, r0y = 0.0, r0z = 0.0;
+        double v0x, v0y, v0z, r0x, r0y, r0z;                         // (defined exactly where they are used: with fuseKick / NextStep)
         if (P.fuseKick || N.xn) { v0x = A.vx[myl]; v0y = A.vy[myl]; v0z = A.vz[myl]; }
         if (N.xn) { r0x = N.R0.x[myl]; r0y = N.R0.y[myl]; r0z = N.R0.z[myl]; }
         double radi = 0.0;
         int ti = 0;
         if (!kOneSpecies) ti = A.type[myl];
         if ((MODE == 0 && P.use_radii) || MODE == 4) radi = A.rad[myl];
-        // ---- gather the candidates (groups of 64; the record padded the last group with a valid atom): all list entries first, then all coordinates
+        // ---- gather the candidates (groups of 64; the record padded the last group with a valid atom).  Four groups are gathered whatever T is (stale
+        // entries are atom indices too: the array starts out zeroed and only indices are ever written), the fifth when T > 256; all loads travel together
         {
-            const int rounds = (T + kWave - 1) >> 6;                   // <= 5
             const int gx0 = lx + P.cx0;
             // does any neighbour cell lie across a periodic boundary (or the seam of a slab ring)?  wave-uniform
             const bool images = gx0 - P.hw[0] < 0 || gx0 + P.hw[0] >= P.nc[0] || cy - P.hw[1] < 0 || cy + P.hw[1] >= ncy || cz - P.hw[2] < 0 || cz + P.hw[2] >= ncz;
-            double gx[kRounds], gy[kRounds], gz[kRounds], grad[kRounds];
-            int gtyp[kRounds];
-            ent[kRounds - 1] = 0u;
-            if (rounds == kRounds) ent[kRounds - 1] = myList[(kRounds - 1) * kWave];
-            // the first four groups are gathered whatever T is (stale entries are atom indices too: the array starts out zeroed and only indices are ever
-            // written); only the fifth is conditional
-#pragma unroll
-            for (int u = 0; u < kRounds; u++)
-                if (u < kRounds - 1 || rounds == kRounds)
-                {
-                    const int j = (int)(ent[u] & 0x3FFFFFFu);
-                    gx[u] = ld_f64(A.x, j); gy[u] = ld_f64(A.y, j); gz[u] = ld_f64(A.z, j);
-                    if (!kOneSpecies) gtyp[u] = ld_i32(A.type, j);
-                    if ((MODE == 0 && P.use_radii) || MODE == 4) grad[u] = ld_f64(A.rad, j);
-                    else grad[u] = 0.0;
+            struct Cand { double x, y, z, rad; int typ; };
+            auto fetch = [&](uint32_t e) {
+                Cand c;
+                const int j = (int)(e & 0x3FFFFFFu);
+                c.x = ld_f64(A.x, j); c.y = ld_f64(A.y, j); c.z = ld_f64(A.z, j);
+                c.typ = kOneSpecies ? 0 : ld_i32(A.type, j);
+                c.rad = ((MODE == 0 && P.use_radii) || MODE == 4) ? ld_f64(A.rad, j) : 0.0;
+                return c;
+            };
+            auto put = [&](int u, uint32_t e, const Cand& c) {
+                double xj = c.x, yj = c.y, zj = c.z;
+                if (images)
+                {   // image code per axis: 0 -> -L, 1 -> 0, 2 -> +L (exact: the product is +-L or 0)
+                    xj += (double)((int)((e >> 26) & 3u) - 1) * P.L[0];
+                    yj += (double)((int)((e >> 28) & 3u) - 1) * P.L[1];
+                    zj += (double)((int)((e >> 30) & 3u) - 1) * P.L[2];
                 }
-#pragma unroll
-            for (int u = 0; u < kRounds; u++)
-                if (u < kRounds - 1 || rounds == kRounds)
-                {
-                    double xj = gx[u], yj = gy[u], zj = gz[u];
-                    if (images)
-                    {
-                        const int c0 = (ent[u] >> 26) & 3, c1 = (ent[u] >> 28) & 3, c2 = (ent[u] >> 30) & 3;
-                        xj += c0 == 0 ? -P.L[0] : (c0 == 2 ? P.L[0] : 0.0);
-                        yj += c1 == 0 ? -P.L[1] : (c1 == 2 ? P.L[1] : 0.0);
-                        zj += c2 == 0 ? -P.L[2] : (c2 == 2 ? P.L[2] : 0.0);
-                    }
-                    const int pq = u * kWave + lane;
-                    txyz[pq] = xj - cc0; txyz[kTileLds + pq] = yj - cc1; txyz[2 * kTileLds + pq] = zj - cc2;
-                    if (!kOneSpecies) ttyp[pq] = (uint8_t)gtyp[u];
-                    if (kRadii) trad[pq] = grad[u];
-                }
+                const int pq = u * kWave + lane;
+                txyz[pq] = xj - cc0; txyz[kTileLds + pq] = yj - cc1; txyz[2 * kTileLds + pq] = zj - cc2;
+                if (!kOneSpecies) ttyp[pq] = (uint8_t)c.typ;
+                if (kRadii) trad[pq] = c.rad;
+            };
+            const Cand c0 = fetch(ent[0]), c1 = fetch(ent[1]), c2 = fetch(ent[2]), c3 = fetch(ent[3]);
+            if (T > 4 * kWave)
+            {
+                const Cand c4 = fetch(ent[4]);
+                put(0, ent[0], c0); put(1, ent[1], c1); put(2, ent[2], c2); put(3, ent[3], c3); put(4, ent[4], c4);
+            }
+            else { put(0, ent[0], c0); put(1, ent[1], c1); put(2, ent[2], c2); put(3, ent[3], c3); }
         }
         const double xi = validI ? xr - cc0 : 1e30, yi = validI ? yr - cc1 : 1e30, zi = validI ? zr - cc2 : 1e30;
         __builtin_amdgcn_wave_barrier();

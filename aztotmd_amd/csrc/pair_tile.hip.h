@@ -890,6 +890,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                 if (lane == 0)
                 {
                     L.meta[2 * cell] = usable ? (T | (nIter << 12)) : -1;
+                    if (P.pad0 & 2097152) { atomicAdd(&L.noList[3], nIter); atomicAdd(&L.noList[4], T); atomicAdd(&L.noList[5], nthis); }      // measurement aid (slow)
                     if (!usable) { atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
                 }
                 continue;                                          // no forces here: k_pair_list computes them
