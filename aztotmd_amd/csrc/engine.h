@@ -160,6 +160,9 @@ private:
     struct GraphSlot { BufState before, after; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
     std::vector<GraphSlot> graphs_;
     BufState buf_state() const;
+    GraphSlot* graph_for_state(int cycle);
+    int graph_cycle() const;
+    bool can_graph() const;
     void set_buf_state(const BufState& b);
     bool capturing_ = false;
     // next-step fusion (pair_tile.hip.h NextStep): on plain NVE steps of a lazy run on one GPU the pair kernel's epilogue also does the next step's
@@ -169,6 +172,10 @@ private:
     bool fuseNext_ = false;         // the pair kernel of the step being launched fuses
     bool preIntegrated_ = false;    // the step being launched was opened by the previous step's pair kernel: no k_integrate1_bin
     int stepsLeftInRun_ = 0;        // steps that follow the one being launched before the host looks / the cycle ends
+    // a sort interval may run on from one aztot_step call into the next (one GPU, pair lists): the lists recorded at the last rebuild are those of the
+    // arrays as they stand; set_state / aztot_forces end that
+    bool listsValid_ = false;
+    void prepare_next_call();
 };
 
 void check_hip(hipError_t e, const char* what);

@@ -723,14 +723,13 @@ void Engine::launch_pair()
                 {
                     HIP_CHECK(hipMemsetAsync(dNoList_ + 2, 0, sizeof(int32_t), stream_));     // cells without a list: counted anew
                     timed("build_lists", [&] { launch_build_lists(Q, S_, dPots_, cur(), dCounts_, dCellStart_, stream_, PairRange(), pl); });
+                    listsValid_ = true;
                 }
                 NextStep nx;
-                if (fuseNextOk_)
-                {
-                    nx.st = dStats_; nx.cnt = dCounts_; nx.R0 = ref_;
-                    if (fuseNext_) { nx.xn = altXyz_[cur_][0]; nx.yn = altXyz_[cur_][1]; nx.zn = altXyz_[cur_][2]; }
-                    else nx.pendingAfter = lazyKick_ ? 1 : -1;
-                }
+                nx.st = dStats_; nx.cnt = dCounts_; nx.R0 = ref_;
+                if (fuseNext_) { nx.xn = altXyz_[cur_][0]; nx.yn = altXyz_[cur_][1]; nx.zn = altXyz_[cur_][2]; }
+                else nx.pendingAfter = lazyKick_ ? 1 : -1;         // this step's second half-kick is owed to the next k_integrate1_bin (a call may open
+                                                                    // with a plain step, where no scan re-arms the flag)
                 timed("pair_list", [&] { splitBlocks_ = launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, nx); });
                 timed("pair_cleanup", [&] { splitBlocks_ += launch_pair_cleanup(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, nx); });
                 if (fuseNext_)
@@ -846,6 +845,7 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
     });
     cur_ ^= 1;
     sinceSort_ = 0;
+    listsValid_ = false;            // (until this step's launch_pair records them)
     if (nranks_ > 1 && lazyOn_ && lazyK_ > 1)
     {   // where the boundary layers sit in the sorted arrays: [ownedBegin, end of layer 2hw-1) goes left, [start of layer ncx-2hw, ownedEnd) goes right;
         // ghosts are [0, ownedBegin) and [ownedEnd, nTotal).  One small read-back per sort.
@@ -882,7 +882,9 @@ void Engine::collect_and_finalize(unsigned slotMask)
 
 void Engine::forces(bool withBonded)
 {
+    sinceSort_ = 1 << 30;           // a sort interval does not run on through a force call (it re-bins wrapped coordinates)
     sort_and_forces(0, withBonded);
+    sinceSort_ = 1 << 30; listsValid_ = false;
     // energies of this configuration; kinetic energy and wall counters are left untouched
     unsigned mask = (1u << PS_EVDW) | (1u << PS_ECOUL) | (1u << PS_DROPPED);
     if (hasBonded_ && withBonded) mask |= (1u << PS_EBOND) | (1u << PS_EANGLE);
@@ -980,6 +982,62 @@ void Engine::step(int nsteps)
     sync();
     check_overflow();
     if (lazyOn_) adapt_sort_interval();
+    prepare_next_call();
+}
+
+// steps per graph: one sort interval; with the cells rebuilt every step the sort ping-pongs the buffers, so it takes two steps to come back
+int Engine::graph_cycle() const
+{
+    const int K = lazyOn_ ? lazyK_ : 1;
+    return (K == 1) ? 2 : K;
+}
+
+bool Engine::can_graph() const
+{
+    // slab ranks: only with the loopback transport and only on request (debug bit 4096) - an experiment, see DESIGN.md section 6
+    const bool slabGraph = nranks_ > 1 && ownedXch_ && (opt_.reserved[0] & 4096) && !(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE);
+    return opt_.use_graph && (nranks_ == 1 || slabGraph) && !profile_;
+}
+
+// the graph of one cycle of steps for the buffer state the engine is in (captured on first use; the capture executes nothing).  One graph per buffer
+// state because kernel arguments are baked in at capture time; a graph starts with a step that sorts
+Engine::GraphSlot* Engine::graph_for_state(int cycle)
+{
+    if (graphCycle_ != cycle) { destroy_graphs(); graphCycle_ = cycle; }
+    const BufState now = buf_state();
+    for (GraphSlot& g : graphs_)
+        if (g.before.cur == now.cur && g.before.xyz[0][0] == now.xyz[0][0] && g.before.xyz[1][0] == now.xyz[1][0]) return &g;
+    GraphSlot g;
+    g.before = now;
+    const int sinceBefore = sinceSort_;
+    HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    capturing_ = true;
+    try
+    {
+        sinceSort_ = 1 << 30;
+        preIntegrated_ = false;
+        for (int k = 0; k < cycle; k++) { stepsLeftInRun_ = cycle - 1 - k; launch_step_kernels(); }
+    }
+    catch (...)
+    {   // leave neither the stream in capture mode nor the engine believing it is capturing
+        hipGraph_t broken = nullptr;
+        (void)hipStreamEndCapture(stream_, &broken);
+        if (broken) (void)hipGraphDestroy(broken);
+        capturing_ = false;
+        preIntegrated_ = false;
+        sinceSort_ = sinceBefore;
+        set_buf_state(now);
+        throw;
+    }
+    capturing_ = false;
+    HIP_CHECK(hipStreamEndCapture(stream_, &g.graph));
+    HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    g.after = buf_state();
+    set_buf_state(now);               // the capture itself executed nothing
+    sinceSort_ = sinceBefore;
+    stepsLeftInRun_ = 0;
+    graphs_.push_back(g);
+    return &graphs_.back();
 }
 
 void Engine::run_steps(int nsteps)
@@ -991,52 +1049,19 @@ void Engine::run_steps(int nsteps)
     // wall crossings when they happen, and check every atom's displacement; should one ever leave the slack (the interval is sized with a factor 2 to
     // spare from the largest step seen), the pair kernels reach one cell further until the next sort - slower, still exact.  The first step of
     // every call sorts (the deferred half-kick is re-armed by the scan).
-    sinceSort_ = 1 << 30;
-    const int K = lazyOn_ ? lazyK_ : 1;
-    const int cycle = (K == 1) ? 2 : K;          // steps per graph: the sort ping-pongs the buffers, so K = 1 takes two steps to come back
-    // slab ranks: only with the loopback transport and only on request (debug bit 4096) - an experiment, see DESIGN.md section 6
-    const bool slabGraph = nranks_ > 1 && ownedXch_ && (opt_.reserved[0] & 4096) && !(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE);
-    const bool can_graph = opt_.use_graph && (nranks_ == 1 || slabGraph) && !profile_;
-    if (can_graph && nsteps >= cycle)
+    // One GPU with pair lists: a sort interval runs on from the previous call when nothing has touched the state since (the lists are those of the arrays
+    // as they stand); the plain steps that finish it are launched one by one, whole cycles are replayed as graphs after that.
+    const bool carryOn = lazyOn_ && nranks_ == 1 && listsOn_ && listsValid_ && lazyK_ > 1 && sinceSort_ < (1 << 29) && pair_variant() == 2;
+    if (!carryOn) sinceSort_ = 1 << 30;
+    preIntegrated_ = false;
+    while (carryOn && done < nsteps && sinceSort_ < lazyK_ - 1) { stepsLeftInRun_ = nsteps - 1 - done; launch_step_kernels(); done++; }
+    const int cycle = graph_cycle();
+    if (can_graph() && nsteps - done >= cycle)
     {
-        // one graph per buffer state because kernel arguments are baked in at capture time; a graph starts with a step that sorts
-        if (graphCycle_ != cycle) { destroy_graphs(); graphCycle_ = cycle; }
+        sinceSort_ = 1 << 30;
         while (nsteps - done >= cycle)
         {
-            const BufState now = buf_state();
-            GraphSlot* slot = nullptr;
-            for (GraphSlot& g : graphs_)
-                if (g.before.cur == now.cur && g.before.xyz[0][0] == now.xyz[0][0] && g.before.xyz[1][0] == now.xyz[1][0]) { slot = &g; break; }
-            if (!slot)
-            {
-                GraphSlot g;
-                g.before = now;
-                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-                capturing_ = true;
-                try
-                {
-                    sinceSort_ = 1 << 30;
-                    preIntegrated_ = false;
-                    for (int k = 0; k < cycle; k++) { stepsLeftInRun_ = cycle - 1 - k; launch_step_kernels(); }
-                }
-                catch (...)
-                {   // leave neither the stream in capture mode nor the engine believing it is capturing
-                    hipGraph_t broken = nullptr;
-                    (void)hipStreamEndCapture(stream_, &broken);
-                    if (broken) (void)hipGraphDestroy(broken);
-                    capturing_ = false;
-                    preIntegrated_ = false;
-                    set_buf_state(now);
-                    throw;
-                }
-                capturing_ = false;
-                HIP_CHECK(hipStreamEndCapture(stream_, &g.graph));
-                HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-                g.after = buf_state();
-                set_buf_state(now);               // the capture itself executed nothing
-                graphs_.push_back(g);
-                slot = &graphs_.back();
-            }
+            GraphSlot* slot = graph_for_state(cycle);
             HIP_CHECK(hipGraphLaunch(slot->exec, stream_));
             done += cycle;
             set_buf_state(slot->after);           // one sort per cycle (K > 1) and the coordinate-array swaps of the fused steps
@@ -1046,6 +1071,27 @@ void Engine::run_steps(int nsteps)
     preIntegrated_ = false;
     for (; done < nsteps; done++) { stepsLeftInRun_ = nsteps - 1 - done; launch_step_kernels(); }
     stepsLeftInRun_ = 0;
+}
+
+// At the end of a call: what the next call will need and this one can provide without executing a step.  (1) The graph of a whole cycle for the buffer
+// state the engine is in (capturing executes nothing).  (2) If the cells were rebuilt by the last step but no lists were recorded (the interval was 1
+// until now: the engine had not measured the atoms' speed yet), the lists of the arrays as they stand - so that the next call opens with plain steps
+// instead of rebuilding the same cells again.
+void Engine::prepare_next_call()
+{
+    if (!lazyOn_ || !lazyMeasured_) return;
+    if (nranks_ == 1 && listsOn_ && lazyK_ > 1 && !listsValid_ && sinceSort_ == 0 && pair_variant() == 2)
+    {
+        PairLists pl;
+        pl.cand = dCandList_; pl.meta = dListMeta_; pl.pairs = dPairList_; pl.laneCnt = dLaneCnt_; pl.noList = dNoList_;
+        P_.cycleStep = 0;
+        HIP_CHECK(hipMemsetAsync(dNoList_ + 2, 0, sizeof(int32_t), stream_));
+        launch_build_lists(P_, S_, dPots_, cur(), dCounts_, dCellStart_, stream_, PairRange(), pl);
+        check_launch("list building");
+        sync();
+        listsValid_ = true;
+    }
+    if (can_graph()) (void)graph_for_state(graph_cycle());
 }
 
 // the largest step any atom made since the last look sizes the next calls' sort interval: K steps of that length use at most half the slack
@@ -1271,6 +1317,7 @@ int Engine::cell_table(int32_t dims[3], int32_t* cellStart, int capCells, int32_
 void Engine::set_state(const aztot_state& in)
 {
     sync();
+    sinceSort_ = 1 << 30; listsValid_ = false;       // the next call rebuilds the cells
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
     const int n = c.ownedEnd - c.ownedBegin;
