@@ -615,6 +615,49 @@ def test_next_step_fused_into_the_pair_kernel(kind):
         assert rel_err(sa[k], so[k]) < 1e-8, (k, rel_err(sa[k], so[k]))
 
 
+def test_sort_interval_runs_on_across_calls():
+    """One GPU, pair lists: the interval between two rebuilds of the cell list does not end with an aztot_step call - 40 single-step calls rebuild the cells
+    as rarely as one 40-step call does (counted through the kernel timers), the lists made at the last rebuild stay in force, and the trajectory is
+    the same (summation order aside) as that of the single call and of the oracle.  aztot_set_state and aztot_forces end the interval: the next step
+    rebuilds."""
+    case = inputs.lj_case((8, 8, 8), a=5.6, seed=51, rc=7.5, cell_list=7.9, vel_T=60.0)
+    a, b = engine(case, pair_variant=2), engine(case, pair_variant=2)
+    o = oracle.Oracle(case)
+    o.forces(1)
+    a.step(10); b.step(10); o.step(10)            # the engines measure the atoms' speed and settle on an interval
+    K = a.stats()["sort_interval"]
+    assert K >= 8 and b.stats()["sort_interval"] == K and a.stats()["pair_lists"] == 1
+    a.set_profile(1); b.set_profile(1)
+    a.reset_kernel_times(); b.reset_kernel_times()
+    for _ in range(40):
+        a.step(1)
+    b.step(40); o.step(40)
+    ka, kb = a.kernel_times(), b.kernel_times()
+    rebuilds_a = ka.get("integrate1_bin", {"calls": 0})["calls"]
+    rebuilds_b = kb.get("integrate1_bin", {"calls": 0})["calls"]
+    assert rebuilds_a <= 40 // K + 1 and rebuilds_b <= 40 // K + 1, (K, rebuilds_a, rebuilds_b)
+    assert ka["pair_list"]["calls"] == 40 and "pair_tile" not in ka
+    sa, sb, so = a.state(), b.state(), o.state()
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(sa[k], sb[k]) < 1e-9, (k, rel_err(sa[k], sb[k]))
+        assert rel_err(sa[k], so[k]) < 1e-9, (k, rel_err(sa[k], so[k]))
+    for k in ("engVdW", "engKin", "engTot"):
+        assert abs(a.stats()[k] - b.stats()[k]) <= 1e-10 * abs(b.stats()[k])
+    # a state upload ends the interval: the next step rebuilds the cells (and its lists) from what was uploaded
+    a.reset_kernel_times()
+    a.set_state(x=sa["x"], y=sa["y"], z=sa["z"])
+    a.step(1)
+    assert a.kernel_times()["integrate1_bin"]["calls"] == 1
+    a.reset_kernel_times()
+    a.forces()
+    a.step(1)
+    assert a.kernel_times()["integrate1_bin"]["calls"] == 1
+    b.step(2); o.step(2)
+    sa, so = a.state(), o.state()
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(sa[k], so[k]) < 1e-9, (k, rel_err(sa[k], so[k]))
+
+
 def test_tile_and_atom_kernels_agree_bitwise_on_energy_scale():
     case = inputs.config("F3")
     a, b = engine(case, pair_variant=1), engine(case, pair_variant=2)
