@@ -129,7 +129,7 @@ struct StepParams
     int32_t fuseKick;             // 1: the pair kernel also applies the second half-kick and books the kinetic energy (plain NVE steps)
     int32_t vdwFamily;            // pad1 == 2: the one potential type all defined species pairs share (1 lnjs, 2 buck, 3 p746, 4 bmhs)
     int32_t cycleStep;            // lazy re-sort: which step since the last rebuild of the cells this launch belongs to (0: the rebuilding step itself)
-    int32_t pad2;
+    int32_t pad2;                 // 1: plain steps may skip the per-atom displacement check while the displacement bound allows (Counts::cycMaxRun)
     double lazySlack2;            // lazy re-sort: square of the displacement an atom may have since the last sort ((hw * cell edge - rc) / 2 per axis, minimum);
                                   // 0: the cells are rebuilt every step
     double pruneR2;               // tile kernels: atoms farther than this (squared) from the centre cell's box are not staged: (rc + 2 slack)^2

@@ -219,6 +219,7 @@ void Engine::construct()
         // instead of 63 + 76 MB per step) for no gain, so large systems fold it into the next step's streaming k_integrate1_bin.
         fuseEpilogue_ = plainNve && variant >= 2 && capacity_ <= kFuseKickMaxAtoms && !(opt_.reserved[0] & 256);   // debug bit 256: large-system path
         lazyKick_ = plainNve && !fuseEpilogue_;
+        P_.pad2 = 0;
         // next-step fusion (NextStep, pair_tile.hip.h): plain NVE (nothing happens between the forces and the next half-kick; on slab ranks the coordinate
         // exchange of the next step simply follows the pair kernel that produced the coordinates), a lazy run that walks
         // pair lists; debug bit 131072 switches it off.  Up to ~500 000 atoms per GPU, where a step is bound by launch latency (measured: 40 000 atoms 0.0230 ->
@@ -239,6 +240,9 @@ void Engine::construct()
                 }
         }
     }
+    // displacement bound instead of the per-atom check on plain steps: wherever k_integrate1_bin<2> opens every plain step (engines that fuse the next
+    // step into the pair kernel keep the per-atom check there); debug bit 524288 switches it off
+    P_.pad2 = (lazyOn_ && !fuseNextOk_ && !(opt_.reserved[0] & 524288)) ? 1 : 0;
     if (nranks_ > 1 && !xch_)
     {   // options.reserved[1]: loopback measurement mode (see LoopbackExchanger)
         ownedXch_.reset(new LoopbackExchanger((P_.ncxLocal - 2 * P_.hw[0]) * P_.csz[0], P_.L[0], lay_.mig_offset(), lay_.halo_offset(),

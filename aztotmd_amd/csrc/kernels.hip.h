@@ -309,6 +309,11 @@ struct Counts
                                     // ahead -, cleared on rebuild steps): from that step on the pair kernels widen their stencil by one cell until the next rebuild
     int32_t lazyViolatedEver;       // sticky copy for the host, which then shortens the sort interval
     unsigned long long maxStep2;    // bit pattern of the largest |v dt|^2 of any atom since the host last looked (non-negative doubles order like integers)
+    // Displacement bound of the lazy re-sort (k_integrate1_bin<2>): on plain step s no atom can be farther from where it was at the last rebuild than
+    // (s - 1) x the longest step made since + its own step, so while that stays inside the slack the per-atom check against the reference position - 24 B
+    // per atom and step - is not needed.  cycMaxRun only ever grows between two rebuilds (a value read while a launch is still raising it is still an upper
+    // bound of everything earlier); a rebuild lets it decay by 10 % instead of clearing it, so that only the few workgroups with a new record issue an atomic.
+    unsigned long long cycMaxRun;   // bit pattern of (an upper bound of) the largest |v dt|^2 since the last rebuild
 };
 
 // has an atom left its cell's slack as of the step this launch belongs to?
@@ -360,7 +365,15 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
                                                                            // read only by the thermostat kernels at the end of the step
     double eField = 0.0, mom[6] = {0, 0, 0, 0, 0, 0}, cross[6] = {0, 0, 0, 0, 0, 0}, stepLen2 = 0.0;
     int anyCross = 0, myCell = 0, myLayer = 0, violated = 0;
-    if (STEPMODE == 1 && blockIdx.x == 0 && threadIdx.x == 0) cnt->lazyViolated = 0;      // the cells are rebuilt in this step
+    if (STEPMODE == 1 && blockIdx.x == 0 && threadIdx.x == 0)
+    {   // the cells are rebuilt in this step: nobody has moved since
+        cnt->lazyViolated = 0;
+        cnt->cycMaxRun = (unsigned long long)__double_as_longlong(0.81 * __longlong_as_double((long long)cnt->cycMaxRun));
+    }
+    // plain step s: what the atoms can have moved by before this step
+    double roomLeft = -1.0;                                          // < 0: check every atom against its reference position
+    if (STEPMODE == 2 && P.pad2)
+        roomLeft = sqrt(P.lazySlack2) - (double)(P.cycleStep - 1) * sqrt(__longlong_as_double((long long)__hip_atomic_load(&cnt->cycMaxRun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
     if (i < end)
     {
         const int t = A.type[i];
@@ -395,9 +408,13 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
             if (c < 0) { mom[4] = m * (-vz); cross[4] = 1; anyCross = 1; } else if (c > 0) { mom[5] = m * vz; cross[5] = 1; anyCross = 1; }
             if (BIN) { wrap_coord(x, P.L[0], P.invL[0]); wrap_coord(y, P.L[1], P.invL[1]); wrap_coord(z, P.L[2], P.invL[2]); }
             else
-            {   // plain step: has the atom left the slack of the cell it was sorted into?
-                const double ex = x - R0.x[i], ey = y - R0.y[i], ez = z - R0.z[i];
-                if (ex * ex + ey * ey + ez * ez > P.lazySlack2) violated = 1;
+            {   // plain step: has the atom left the slack of the cell it was sorted into?  Certainly not while the longest steps since the rebuild plus
+                // its own add up to less than the slack; otherwise look at where it was
+                if (!(roomLeft > 0.0 && stepLen2 < roomLeft * roomLeft))
+                {
+                    const double ex = x - R0.x[i], ey = y - R0.y[i], ez = z - R0.z[i];
+                    if (ex * ex + ey * ey + ez * ez > P.lazySlack2) violated = 1;
+                }
             }
             if (anyCross)
             {   // per-species crossing counters: specAcBoxNeg / specAcBoxPos of put_periodic (cuMDfunc.cu:35-106), the columns of
@@ -424,6 +441,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
         {   // thousands of workgroups on one word would serialise (~90 atomics per microsecond): look first, only a new maximum is published
             const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
             if (bits > __hip_atomic_load(&cnt->maxStep2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cnt->maxStep2, bits);
+            if (STEPMODE == 2 && P.pad2 && bits > __hip_atomic_load(&cnt->cycMaxRun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cnt->cycMaxRun, bits);
         }
         if (!BIN && __syncthreads_or(violated) && threadIdx.x == 0)
         {   // (an earlier violation keeps its step; all writers of one launch write the same value)

@@ -30,8 +30,9 @@ FP64_VECTOR_PEAK = 78.6e12   # FLOP/s, FP64 vector (256 CUs x 128 FLO
 PAIR_BYTES_PER_ATOM = 52.0   # x,y,z,type read + fx,fy,fz written
 PAIR_BYTES_PER_CELL = 8.0    # cellStart/cellCount
 # algorithmic bytes per atom of the streaming kernels: the ones for which ">= 40 % of HBM peak" is the meaningful target
-STREAM_BYTES_PER_ATOM = {"integrate1_bin": 132.0, "integrate1": 148.0, "place": 28.0, "rank_gather": 144.0, "integrate2": 76.0, "post_tstat": 84.0}
-# (integrate1 = a plain step of the lazy re-sort: no cell id / slot written (-8), reference position read (+24); rank_gather also writes that reference (+24))
+STREAM_BYTES_PER_ATOM = {"integrate1_bin": 132.0, "integrate1": 124.0, "place": 28.0, "rank_gather": 144.0, "integrate2": 76.0, "post_tstat": 84.0}
+# (integrate1 = a plain step of the lazy re-sort: no cell id / slot written (-8); the reference position (24 B) is read only for atoms the displacement
+#  bound cannot clear - none in a normal run; rank_gather writes that reference (+24))
 
 
 def parse():
