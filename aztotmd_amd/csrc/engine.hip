@@ -921,7 +921,15 @@ void Engine::launch_step_kernels()
     const bool fused = fuseNow_;                 // launch_pair drops the request if the tile kernel is not the one running
     fuseNow_ = false;
     ekinFromPair_ = fused;
-    if (!fused && !lazyKick_)
+    // radiative thermostat without equilibration scaling: nothing global happens between the second half-kick and the thermostat - one launch (debug bit
+    // 4194304: two, as everywhere else)
+    const bool kickAndPost = !fused && !lazyKick_ && !equil && P_.tstat == AZTOT_TSTAT_RADI && !(opt_.reserved[0] & 4194304);
+    if (kickAndPost)
+        timed("integrate2_post", [&] {
+            hipLaunchKernelGGL(k_integrate2_post, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal, dPartials_,
+                               maxBlocks_, dStats_, dPhotons_, dUvx_, dUvy_, dUvz_);
+        });
+    else if (!fused && !lazyKick_)
         timed("integrate2", [&] {
             hipLaunchKernelGGL(k_integrate2, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal, dPartials_,
                                maxBlocks_, dStats_);
@@ -941,7 +949,7 @@ void Engine::launch_step_kernels()
         }
         timed("scale_decision", [&] { hipLaunchKernelGGL(k_scale_decision, dim3(1), dim3(64), 0, stream_, P_, dStats_, dEkGlobal_); });
     }
-    if (equil || P_.tstat == AZTOT_TSTAT_RADI)
+    if ((equil || P_.tstat == AZTOT_TSTAT_RADI) && !kickAndPost)
         timed("post_tstat", [&] {
             hipLaunchKernelGGL(k_post, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dStats_, dPhotons_, dUvx_, dUvy_, dUvz_,
                                dPartials_, maxBlocks_);

@@ -658,6 +658,29 @@ def test_sort_interval_runs_on_across_calls():
         assert rel_err(sa[k], so[k]) < 1e-9, (k, rel_err(sa[k], so[k]))
 
 
+def test_kick_and_radiative_thermostat_in_one_launch():
+    """Radiative thermostat without equilibration scaling: k_integrate2 and k_post run as ONE launch (nothing global happens between the second half-kick and
+    the thermostat).  Same operations in the same order: bit-identical to the two-launch form (debug bit 4194304), per-atom internal energies and radii
+    included, and equal to the oracle."""
+    case = inputs.lj_case((6, 6, 6), a=5.6, seed=61, rc=7.0, cell_list=7.5, vel_T=150.0, T=150.0, tstat="radi", radii=[(2.73, 4.731, 0.2)])
+    a = engine(case, pair_variant=2)
+    b = engine(case, pair_variant=2, debug=4194304)
+    o = oracle.Oracle(case)
+    o.forces(1)
+    for n in (3, 20, 1, 16):
+        a.step(n); b.step(n); o.step(n)
+    a.set_profile(1); a.reset_kernel_times(); a.step(2); b.step(2); o.step(2)
+    kt = a.kernel_times()
+    assert "integrate2_post" in kt and "post_tstat" not in kt and "integrate2" not in kt, sorted(kt)
+    sa, sb, so = a.state(), b.state(), o.state()
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz", "U", "radius"):
+        assert np.array_equal(sa[k], sb[k]), (k, rel_err(sa[k], sb[k]))
+        ko = "rad" if k == "radius" else k
+        assert rel_err(sa[k], so[ko]) < 1e-8, (k, rel_err(sa[k], so[ko]))
+    for k in ("engKin", "engTemp", "engTot"):
+        assert a.stats()[k] == b.stats()[k], (k, a.stats()[k], b.stats()[k])
+
+
 def test_tile_and_atom_kernels_agree_bitwise_on_energy_scale():
     case = inputs.config("F3")
     a, b = engine(case, pair_variant=1), engine(case, pair_variant=2)
