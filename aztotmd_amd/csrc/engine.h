@@ -126,6 +126,13 @@ private:
     bool listsOn_ = false;          // plain steps run k_pair_list (switched off when too many cells turn out to keep no list)
     int candMode_ = 0;              // for the pair launch in flight: 0 none, 1 record, 2 plain step of the lazy re-sort
     int halo_[5] = {0, 0, 0, 0, 0};  // slab ranks: ownedBegin, end of the left boundary layers, start of the right ones, ownedEnd, nTotal (after the last sort)
+    // read back after every sort without stalling the stream: copied into pinned host memory behind the sort kernels, waited for only when the next plain
+    // step needs the numbers (by then the list building and the pair kernel of the sort step are queued behind the copy)
+    int32_t* hHalo_ = nullptr;       // pinned: {cellStart of the two boundary layers, ownedBegin, ownedEnd, nTotal}
+    int32_t* dHaloInfo_ = nullptr;   // the same on the device, written by k_rank_gather
+    hipEvent_t evHaloInfo_ = nullptr;
+    bool haloInfoPending_ = false;
+    void take_halo_info();
     int graphCycle_ = 0;            // steps held by the captured graphs
     CellBins bins_{};               // per-cell bins of 16 atoms for pair kernel 3 (all-null when that kernel cannot run)
     BondedTables bonded_{};         // all-null when the model has no bonds / angles

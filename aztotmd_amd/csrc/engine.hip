@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -299,6 +300,10 @@ void Engine::release()
     if (evIntegrated_) (void)hipEventDestroy(evIntegrated_);
     if (evHalo_) (void)hipEventDestroy(evHalo_);
     evIntegrated_ = evHalo_ = nullptr;
+    if (evHaloInfo_) (void)hipEventDestroy(evHaloInfo_);
+    evHaloInfo_ = nullptr;
+    if (hHalo_) (void)hipHostFree(hHalo_);
+    hHalo_ = nullptr;
     if (commStream_) { (void)hipStreamSynchronize(commStream_); (void)hipStreamDestroy(commStream_); }
     commStream_ = nullptr;
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -385,6 +390,8 @@ void Engine::allocate()
     if (nranks_ > 1)
     {
         for (int k = 0; k < 4; k++) { dMsg_[k] = (char*)alloc(lay_.bytes()); HIP_CHECK(hipMemsetAsync(dMsg_[k], 0, lay_.bytes(), stream_)); }
+        dHaloInfo_ = (int32_t*)alloc(sizeof(int32_t) * 8);
+        HIP_CHECK(hipMemsetAsync(dHaloInfo_, 0, sizeof(int32_t) * 8, stream_));
     }
     const int ns = model_.nSpec();
     std::vector<DevPot> pots((size_t)ns * ns);
@@ -724,8 +731,7 @@ void Engine::launch_pair()
             {   // lazy re-sort.  The step that rebuilds the cells first makes the lists (candidates of every tile, partners of every atom); then, like every
                 // plain step until the next rebuild, it walks them; the clean-up launch stages the cells that keep no list
                 if (candMode_ == 1)
-                {
-                    HIP_CHECK(hipMemsetAsync(dNoList_ + 2, 0, sizeof(int32_t), stream_));     // cells without a list: counted anew
+                {   // (k_rank_gather has cleared the count of cells without a list)
                     timed("build_lists", [&] { launch_build_lists(Q, S_, dPots_, cur(), dCounts_, dCellStart_, stream_, PairRange(), pl); });
                     listsValid_ = true;
                 }
@@ -754,6 +760,15 @@ void Engine::launch_pair()
         });
     if (variant < 2) fuseNow_ = false;           // only the tile kernels have the fused epilogue (cannot happen: see the constructor)
     pairBlocksUsed_ = (variant == 3) ? pair_quad_grid(P_) : (variant == 2) ? (splitBlocks_ ? splitBlocks_ : pair_tile_grid(P_)) : div_up(capacity_, kBlock);
+}
+
+// slab ranks: where the boundary layers sit in the sorted arrays, as read back behind the last sort
+void Engine::take_halo_info()
+{
+    if (!haloInfoPending_) return;
+    HIP_CHECK(hipEventSynchronize(evHaloInfo_));
+    halo_[0] = hHalo_[2]; halo_[1] = hHalo_[0]; halo_[2] = hHalo_[1]; halo_[3] = hHalo_[3]; halo_[4] = hHalo_[4];
+    haloInfoPending_ = false;
 }
 
 // one message to each x-neighbour: migrants + halo (packed by k_integrate1_bin; protocol in slab.hip.h)
@@ -787,6 +802,7 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
         if (nranks_ > 1)
         {   // the neighbours hold this rank's boundary atoms in the order of the last sort: only their coordinates (and radii) travel
             const int left = (rank_ + nranks_ - 1) % nranks_, right = (rank_ + 1) % nranks_;
+            take_halo_info();
             AtomArrays& A = cur();
             double* arr[4] = {A.x, A.y, A.z, A.rad};
             // The exchange touches the ghost ranges only, and the cells two or more layers inside the slab never read them: it runs on its
@@ -845,7 +861,8 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
     });
     timed("rank_gather", [&] {
         hipLaunchKernelGGL(k_rank_gather, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellStart_, dTmpId_, dTmpSrc_, dTmpCell_, cur(), oth(),
-                           dCellOfSorted_, (P_.tstat == AZTOT_TSTAT_RADI || P_.use_radii || thermoTouched_) ? 2 : 0, P_, dCounts_, bonded_.idxOfId, bins_, ref_);
+                           dCellOfSorted_, (P_.tstat == AZTOT_TSTAT_RADI || P_.use_radii || thermoTouched_) ? 2 : 0, P_, dCounts_, bonded_.idxOfId, bins_, ref_,
+                           dHaloInfo_, (listsOn_ && stepMode == 1 && lazyOn_ && lazyK_ > 1) ? dNoList_ + 2 : nullptr);
     });
     cur_ ^= 1;
     sinceSort_ = 0;
@@ -853,14 +870,14 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
     if (nranks_ > 1 && lazyOn_ && lazyK_ > 1)
     {   // where the boundary layers sit in the sorted arrays: [ownedBegin, end of layer 2hw-1) goes left, [start of layer ncx-2hw, ownedEnd) goes right;
         // ghosts are [0, ownedBegin) and [ownedEnd, nTotal).  One small read-back per sort.
-        const int plane = P_.nc[1] * P_.nc[2], hw = P_.hw[0];
-        int32_t v[2];
-        Counts c;
-        HIP_CHECK(hipMemcpyAsync(&v[0], dCellStart_ + (size_t)2 * hw * plane, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        HIP_CHECK(hipMemcpyAsync(&v[1], dCellStart_ + (size_t)(P_.ncxLocal - 2 * hw) * plane, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        HIP_CHECK(hipMemcpyAsync(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost, stream_));
-        HIP_CHECK(hipStreamSynchronize(stream_));
-        halo_[0] = c.ownedBegin; halo_[1] = v[0]; halo_[2] = v[1]; halo_[3] = c.ownedEnd; halo_[4] = c.nTotal;
+        if (!hHalo_)
+        {
+            HIP_CHECK(hipHostMalloc((void**)&hHalo_, sizeof(int32_t) * 8, hipHostMallocDefault));
+            HIP_CHECK(hipEventCreateWithFlags(&evHaloInfo_, hipEventDisableTiming));
+        }
+        HIP_CHECK(hipMemcpyAsync(hHalo_, dHaloInfo_, sizeof(int32_t) * 5, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipEventRecord(evHaloInfo_, stream_));
+        haloInfoPending_ = true;      // (no stall here: take_halo_info waits when the numbers are needed)
     }
     }
     launch_pair();

@@ -641,7 +641,8 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
                                                         const int32_t* __restrict__ tmpId, const int32_t* __restrict__ tmpSrc,
                                                         const int32_t* __restrict__ tmpCell, AtomArrays src, AtomArrays dst,
                                                         int32_t* __restrict__ cellOfSorted, int carryForces /* bit 0: forces, bit 1: U + radius */, StepParams P, Counts* cntOut,
-                                                        int32_t* __restrict__ idxOfId, CellBins B, RefPos R0)
+                                                        int32_t* __restrict__ idxOfId, CellBins B, RefPos R0, int32_t* __restrict__ haloInfo,
+                                                        int32_t* __restrict__ zeroMe)
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p == 0)
@@ -649,10 +650,17 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
         if (P.nranks > 1)
         {
             const int plane = P.nc[1] * P.nc[2];
-            cntOut->ownedBegin = cellStart[P.hw[0] * plane];
-            cntOut->ownedEnd = cellStart[(P.ncxLocal - P.hw[0]) * plane];
+            const int ob = cellStart[P.hw[0] * plane], oe = cellStart[(P.ncxLocal - P.hw[0]) * plane];
+            cntOut->ownedBegin = ob;
+            cntOut->ownedEnd = oe;
+            if (haloInfo)
+            {   // what the host needs to address the boundary layers in the plain steps' coordinate exchange: one small copy instead of three
+                haloInfo[0] = cellStart[2 * P.hw[0] * plane]; haloInfo[1] = cellStart[(P.ncxLocal - 2 * P.hw[0]) * plane];
+                haloInfo[2] = ob; haloInfo[3] = oe; haloInfo[4] = cnt->nTotal;
+            }
         }
         else { cntOut->ownedBegin = 0; cntOut->ownedEnd = cnt->nTotal; }
+        if (zeroMe) *zeroMe = 0;        // (the list builder's count of cells without a list: cleared here instead of by a memset node of its own)
     }
     if (p >= cnt->nTotal) return;
     const int c = tmpCell[p];
