@@ -1,18 +1,19 @@
-// Pair-force kernel of the plain steps of the lazy re-sort: one wave64 per cell, driven by the lists the last cell rebuild recorded.
+// Pair-force kernel of a lazy run (every step: plain steps and - after the lists have been made - the rebuild steps too): one wave64 per cell,
+// driven by the lists the last rebuild of the cells recorded.
 //
-// Replaces the reference's cell_list5a + cell_list4b_noshared + pair_1 (cuPairs.cu:2266,1474,117) on the steps between two rebuilds of the
-// cell list.  The reference rebuilds everything every step (main.cu:300-326); here the step that rebuilds the cells (k_pair_tile, recording
-// launch) leaves two lists per cell:
+// Replaces the reference's cell_list5a + cell_list4b_noshared + pair_1 (cuPairs.cu:2266,1474,117).  The reference rebuilds everything every step
+// (main.cu:300-326); here the step that rebuilds the cells (BUILD instantiation of k_pair_tile, pair_tile.hip.h) leaves two lists per cell:
 //   * the candidates of the cell's tile (atom index + periodic image code), and
 //   * for every atom of the cell the candidates within rc + 2 slack, dealt round-robin to the lanes that serve the atom.
-// Until the next rebuild atoms keep their slots and nobody moves farther than the slack (checked every step by k_integrate1_bin<2>; a violation
-// makes this kernel stand down and the clean-up launch of k_pair_tile stage everything with a wider stencil), so a plain step is
+// Until the next rebuild atoms keep their slots and nobody moves farther than the slack (checked every step by whoever integrates; a violation
+// makes this kernel stand down and the clean-up launch of k_pair_tile stage everything with a wider stencil), so a step is
 //   1. gather the candidates into LDS (coordinates relative to the cell centre, as in k_pair_tile: same numbers, same arithmetic);
-//   2. every lane walks ITS list: entry -> LDS byte offset -> exact r^2 <= rc^2 test -> potential (pair_body, shared with k_pair_tile).
+//   2. every lane walks ITS list: entry -> LDS byte offset -> exact r^2 <= rc^2 test -> potential (pair_body, shared with k_pair_tile);
+//   3. optionally (NextStep, small systems) the epilogue opens the next step: second half-kick, first half-kick, drift.
 // No run table, no pruning, no compaction, no distance filter, no bit masks; and because an atom's partners were dealt evenly, the lanes of a
-// wave finish together (the mask-popping loop of k_pair_tile runs max-over-lanes = 21 iterations for a mean of 14 on the 1 M-atom box; here 15-16).
+// wave finish together (the mask-popping loop of k_pair_tile runs max-over-lanes = 21 iterations for a mean of 14 on the 1 M-atom box; here 14).
 // Forces: written once per atom, no atomics, fixed summation order => bit-reproducible.  HBM traffic: the lists are streamed once per step
-// (coalesced: 4 B per candidate, 2 B per pair entry), which is what buys the 2x in vector instructions.
+// (coalesced: 4 B per candidate, 2 B per pair entry), which is what buys the 3x in vector instructions.
 #pragma once
 #include "pair_tile.hip.h"
 
