@@ -1025,7 +1025,11 @@ bool Engine::can_graph() const
 {
     // slab ranks: only with the loopback transport and only on request (debug bit 4096) - an experiment, see DESIGN.md section 6
     const bool slabGraph = nranks_ > 1 && ownedXch_ && (opt_.reserved[0] & 4096) && !(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE);
-    return opt_.use_graph && (nranks_ == 1 || slabGraph) && !profile_;
+    // Replaying captured cycles pays where a step is a handful of microsecond kernels.  On 1 M atoms the kernels are long enough for plain asynchronous
+    // launches to keep the GPU busy, and each hipGraphLaunch costs a 40 us bubble in front of its first kernel (rocprofv3 kernel trace): 0.1594 ms/step
+    // replayed, 0.1575 launched one by one; 40 000 atoms: 0.0184 replayed, 0.0187 one by one.  (Debug bit 8388608: replay whatever the size.)
+    const bool worthIt = capacity_ <= 2 * kFuseKickMaxAtoms || (opt_.reserved[0] & 8388608);
+    return opt_.use_graph && worthIt && (nranks_ == 1 || slabGraph) && !profile_;
 }
 
 // the graph of one cycle of steps for the buffer state the engine is in (captured on first use; the capture executes nothing).  One graph per buffer

@@ -50,6 +50,7 @@ def parse():
                     help="engine path switches for A/B measurements: 128 k_integrate2 every step, 256 large-system kick path, 512 generic pair kernel")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="measurement aid: time rank 0 of an N-rank slab run on one GPU (loopback halo)")
     ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels (enables hipGraph replay)")
+    ap.add_argument("--no-graph", action="store_true", help="A/B aid: launch every kernel eagerly instead of replaying captured cycles")
     return ap.parse_args()
 
 
@@ -140,7 +141,7 @@ def main():
     transport = "single GPU"
     try:
         eng = api.Engine(model, device=local_rank, initial_forces=1, pair_variant=a.pair_variant, cell_size=a.cell_size,
-                         use_graph=1, profile=0, slab=slab, debug=a.debug, sort_every=a.sort_every)
+                         use_graph=0 if a.no_graph else 1, profile=0, slab=slab, debug=a.debug, sort_every=a.sort_every)
         if world > 1:
             transport = "RCCL send/recv over xGMI"
         if a.emulate_ranks > 1:
