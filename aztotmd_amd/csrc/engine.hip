@@ -794,6 +794,12 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
     if (stepMode == 2)
     {   // plain step of the lazy re-sort: integrate only; slots, cells and buffers stay as they are
         if (preIntegrated_) preIntegrated_ = false;                 // the previous step's pair kernel has opened this step already (NextStep)
+        else if (nranks_ == 1 && P_.tstat != AZTOT_TSTAT_NOSE && !(opt_.reserved[0] & 16777216))
+            // one GPU (the owned range starts at 0: 16-byte loads are aligned), nothing scales the velocities at the start of the step: two atoms per thread
+            timed("integrate1", [&] {
+                hipLaunchKernelGGL(k_integrate_plain2, dim3(div_up(div_up(capacity_, 2), kBlock)), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dPartials_,
+                                   maxBlocks_, dStats_, ref_);
+            });
         else
         timed("integrate1", [&] {
             hipLaunchKernelGGL(k_integrate1_bin<2>, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellOf_, dSlotOf_,

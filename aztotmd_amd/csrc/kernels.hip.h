@@ -513,6 +513,94 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
     }
 }
 
+// Plain step of the lazy re-sort on one GPU, two atoms per thread with 16-byte loads and stores (k_integrate1_bin<2> moves 8 bytes per lane and request;
+// the arithmetic, its order and every side effect are the same - see there for the commentary).  Requires an even first index and no velocity scaling
+// at the start of the step (Nose-Hoover), which is what Engine checks before choosing it.
+__global__ __launch_bounds__(kBlock) void k_integrate_plain2(StepParams P, SpecTable S, AtomArrays A, Counts* __restrict__ cnt, double* __restrict__ partials, int maxBlocks,
+                                                             DevStats* __restrict__ st, RefPos R0)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int begin = cnt->ownedBegin, end = cnt->ownedEnd;
+    const int i0 = begin + 2 * (blockIdx.x * kBlock + threadIdx.x);
+    const bool pendingKick = st->pendingKick != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->step += 1;
+    double roomLeft = -1.0;
+    if (P.pad2)
+        roomLeft = sqrt(P.lazySlack2) - (double)(P.cycleStep - 1) * sqrt(__longlong_as_double((long long)__hip_atomic_load(&cnt->cycMaxRun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    double mom[6] = {0, 0, 0, 0, 0, 0}, cross[6] = {0, 0, 0, 0, 0, 0}, stepLen2 = 0.0;
+    int anyCross = 0, violated = 0;
+    if (i0 < end)
+    {
+        const bool two = i0 + 1 < end;
+        double x[2], y[2], z[2], vx[2], vy[2], vz[2], fx[2], fy[2], fz[2];
+        int t[2];
+        auto ld2 = [&](const double* p, double (&o)[2]) {
+            if (two) { const double2 v = *(const double2*)(p + i0); o[0] = v.x; o[1] = v.y; }
+            else { o[0] = p[i0]; o[1] = 0.0; }
+        };
+        ld2(A.x, x); ld2(A.y, y); ld2(A.z, z); ld2(A.vx, vx); ld2(A.vy, vy); ld2(A.vz, vz); ld2(A.fx, fx); ld2(A.fy, fy); ld2(A.fz, fz);
+        if (two) { const int2 tt = *(const int2*)(A.type + i0); t[0] = tt.x; t[1] = tt.y; } else { t[0] = A.type[i0]; t[1] = 0; }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+        {
+            if (q == 1 && !two) break;
+            const int i = i0 + q;
+            const double rM = S.rMhdt[t[q]], m = S.mass[t[q]];
+            if (pendingKick) { vx[q] += rM * fx[q]; vy[q] += rM * fy[q]; vz[q] += rM * fz[q]; }
+            vx[q] += rM * fx[q]; vy[q] += rM * fy[q]; vz[q] += rM * fz[q];
+            const int ix0 = image_of(x[q], P.L[0], P.invL[0]), iy0 = image_of(y[q], P.L[1], P.invL[1]), iz0 = image_of(z[q], P.L[2], P.invL[2]);
+            double dx = 0.0, dy = 0.0, dz = 0.0;
+            if (!S.frozen[t[q]]) { dx = vx[q] * P.dt; dy = vy[q] * P.dt; dz = vz[q] * P.dt; x[q] += dx; y[q] += dy; z[q] += dz; }
+            const double len2 = dx * dx + dy * dy + dz * dz;
+            stepLen2 = fmax(stepLen2, len2);
+            bool crossed = false;
+            int c;
+            c = image_of(x[q], P.L[0], P.invL[0]) - ix0;
+            if (c < 0) { mom[0] += m * (-vx[q]); cross[0] += 1; crossed = true; atomicAdd(&st->specCross[t[q] * 6 + 0], 1ULL); }
+            else if (c > 0) { mom[1] += m * vx[q]; cross[1] += 1; crossed = true; atomicAdd(&st->specCross[t[q] * 6 + 1], 1ULL); }
+            c = image_of(y[q], P.L[1], P.invL[1]) - iy0;
+            if (c < 0) { mom[2] += m * (-vy[q]); cross[2] += 1; crossed = true; atomicAdd(&st->specCross[t[q] * 6 + 2], 1ULL); }
+            else if (c > 0) { mom[3] += m * vy[q]; cross[3] += 1; crossed = true; atomicAdd(&st->specCross[t[q] * 6 + 3], 1ULL); }
+            c = image_of(z[q], P.L[2], P.invL[2]) - iz0;
+            if (c < 0) { mom[4] += m * (-vz[q]); cross[4] += 1; crossed = true; atomicAdd(&st->specCross[t[q] * 6 + 4], 1ULL); }
+            else if (c > 0) { mom[5] += m * vz[q]; cross[5] += 1; crossed = true; atomicAdd(&st->specCross[t[q] * 6 + 5], 1ULL); }
+            if (crossed) anyCross = 1;
+            if (!(roomLeft > 0.0 && len2 < roomLeft * roomLeft))
+            {
+                const double ex = x[q] - R0.x[i], ey = y[q] - R0.y[i], ez = z[q] - R0.z[i];
+                if (ex * ex + ey * ey + ez * ez > P.lazySlack2) violated = 1;
+            }
+        }
+        auto st2 = [&](double* p, const double (&o)[2]) {
+            if (two) { double2 v; v.x = o[0]; v.y = o[1]; *(double2*)(p + i0) = v; }
+            else p[i0] = o[0];
+        };
+        st2(A.vx, vx); st2(A.vy, vy); st2(A.vz, vz); st2(A.x, x); st2(A.y, y); st2(A.z, z);
+    }
+    {
+        const double mx = block_max(stepLen2, scratch);
+        if (threadIdx.x == 0)
+        {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
+            if (bits > __hip_atomic_load(&cnt->maxStep2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cnt->maxStep2, bits);
+            if (P.pad2 && bits > __hip_atomic_load(&cnt->cycMaxRun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cnt->cycMaxRun, bits);
+        }
+        if (__syncthreads_or(violated) && threadIdx.x == 0)
+        {
+            if (cnt->lazyViolated == 0) cnt->lazyViolated = max(P.cycleStep, 1);
+            cnt->lazyViolatedEver = 1;
+        }
+    }
+    if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EFIELD, 0.0);
+    if (__syncthreads_or(anyCross))
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+        {
+            const double a = block_sum(mom[k], scratch), b = block_sum(cross[k], scratch);
+            if (threadIdx.x == 0 && b != 0.0) { add_partial(partials, maxBlocks, PS_MOM_XN + k, a); add_partial(partials, maxBlocks, PS_CNT_XN + k, b); }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: exclusive prefix sum of the cell histogram (calc_firstAtomInCell cuSort.cu:130-143 is ONE thread).
 //   k_scan_totals : each workgroup sums its chunk of kScanChunk cells
