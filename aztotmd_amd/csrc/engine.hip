@@ -1206,7 +1206,8 @@ void Engine::adapt_sort_interval()
         std::memcpy(&ms2, &c.maxStep2, sizeof(ms2));
         const double len = std::sqrt(ms2);
         const double raw = len > 0 ? lazySlack_ / ((nranks_ > 1 ? 4.0 : 2.0) * len) : 1e9;
-        static const int allowed[] = {32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
+        if (std::getenv("AZTOT_VERBOSE")) std::fprintf(stderr, "aztot: longest step %.3e A, slack %.3e A: interval up to %.1f steps\n", len, lazySlack_, raw);
+        static const int allowed[] = {32, 28, 24, 20, 16, 14, 12, 10, 8, 6, 5, 4, 3, 2, 1};
         K = 1;
         for (int a : allowed) if (a <= lazyCap_ && (double)a <= raw) { K = a; break; }
     }
