@@ -117,6 +117,25 @@ def test_lazy_resort_at_full_size(name):
     assert max(np.abs(sa[k]).max() for k in ("x", "y", "z")) < max(case["box"]) and min(sa[k].min() for k in ("x", "y", "z")) >= 0.0
 
 
+def test_slack_violation_at_full_size():
+    """1 000 188 atoms at 3 000 K with the interval held at 16 steps (debug bit 8192) although the atoms use up the 0.05 A slack in two or three: atoms
+    DO leave the slack between two rebuilds, the list kernel stands down, and the clean-up launch (one residency's worth of workgroups striding over all
+    74 088 cells) stages every cell with the wider stencil.  Same trajectory as the every-step schedule, summation order aside."""
+    case = inputs.lj_case((63, 63, 63), seed=20240502, vel_T=3000.0)
+    a = api.Engine(api.Model.from_case(case), sort_every=16, debug=8192)
+    b = api.Engine(api.Model.from_case(case), sort_every=1)
+    for n in (10, 22, 5):
+        a.step(n); b.step(n)
+    sa, sb, sta, stb = a.state(), b.state(), a.stats(), b.stats()
+    assert sta["sort_interval"] == 16 and sta["sort_violations"] > 0 and sta["pair_lists"] == 1, sta
+    for k in XVF:
+        assert rel_err(sa[k], sb[k]) < 1e-9, (k, rel_err(sa[k], sb[k]))
+    for k in ("engVdW", "engKin", "engTot"):
+        assert abs(sta[k] - stb[k]) <= 1e-10 * abs(stb[k]) + 1e-12, (k, sta[k], stb[k])
+    for k in ("posCross", "negCross"):
+        assert sta[k] == stb[k]
+
+
 @pytest.mark.parametrize("cell", [2.2, 3.1])
 def test_multi_workgroup_scan_on_a_fine_grid(cell):
     """40 000 atoms (BASELINE config 2) on 2.2 A / 3.1 A cells: 52 x 52 x 65 = 175 760 cells, most of them empty - k_scan_totals +
