@@ -681,6 +681,33 @@ def test_kick_and_radiative_thermostat_in_one_launch():
         assert a.stats()[k] == b.stats()[k], (k, a.stats()[k], b.stats()[k])
 
 
+@pytest.mark.parametrize("generic", [False, True])
+def test_pair_lists_with_thermostat_radii(generic):
+    """Pair lists where the potential depends on per-atom radii the radiative thermostat rewrites every step ('surk', case study 2 style, on cut-off sized
+    cells so that a tile holds the stencil): the list kernel gathers the radii afresh with the coordinates.  Specialised surk mode and the generic
+    switch-based body (debug bit 512) against the every-step schedule and the oracle."""
+    pos, box = inputs.fcc_positions((7, 7, 7), 5.8, 0.1, 15)
+    N = len(pos)
+    case = {"box": box.tolist(), "dt": 0.001, "species": [(39.9, 0.0)], "names": ["Ar"], "types": np.zeros(N, dtype=np.int32),
+            "vdw": [(0, 0, 7, 6.0, [75.0, 8.0, 1.0, 1.0])], "radii": [(2.73, 4.731, 0.2)], "x": pos[:, 0].copy(), "y": pos[:, 1].copy(),
+            "z": pos[:, 2].copy(), "vx": np.zeros(N), "vy": np.zeros(N), "vz": np.zeros(N), "T": 300.0, "tstat_type": 2,
+            "cell_list": 6.5, "use_clist": 1, "elec_type": 0}
+    dbg = 512 if generic else 0
+    a = engine(case, debug=dbg)
+    b = engine(case, debug=dbg, sort_every=1)
+    o = oracle.Oracle(case)
+    o.forces(1)
+    for n in (10, 25, 6):
+        a.step(n); b.step(n); o.step(n)
+    sta = a.stats()
+    assert sta["pair_lists"] == 1 and sta["sort_interval"] > 1 and sta["cells_without_list"] == 0, sta
+    sa, sb, so = a.state(), b.state(), o.state()
+    for k, ko in (("x", "x"), ("vx", "vx"), ("fx", "fx"), ("fz", "fz"), ("U", "U"), ("radius", "rad")):
+        assert rel_err(sa[k], sb[k]) < 1e-9, (k, rel_err(sa[k], sb[k]))
+        assert rel_err(sa[k], so[ko]) < 1e-9, (k, rel_err(sa[k], so[ko]))
+    assert abs(sta["engVdW"] - o.stats()["engVdW"]) <= 1e-10 * abs(o.stats()["engVdW"])
+
+
 def test_tile_and_atom_kernels_agree_bitwise_on_energy_scale():
     case = inputs.config("F3")
     a, b = engine(case, pair_variant=1), engine(case, pair_variant=2)
