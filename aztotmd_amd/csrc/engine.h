@@ -182,6 +182,7 @@ private:
     // a sort interval may run on from one aztot_step call into the next (one GPU, pair lists): the lists recorded at the last rebuild are those of the
     // arrays as they stand; set_state / aztot_forces end that
     bool listsValid_ = false;
+    bool carryAgreed_ = false;      // slab ranks: every rank can carry the interval on (decided together at the end of the previous call)
     void prepare_next_call();
 };
 

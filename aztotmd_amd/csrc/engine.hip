@@ -911,7 +911,7 @@ void Engine::forces(bool withBonded)
 {
     sinceSort_ = 1 << 30;           // a sort interval does not run on through a force call (it re-bins wrapped coordinates)
     sort_and_forces(0, withBonded);
-    sinceSort_ = 1 << 30; listsValid_ = false;
+    sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false;
     // energies of this configuration; kinetic energy and wall counters are left untouched
     unsigned mask = (1u << PS_EVDW) | (1u << PS_ECOUL) | (1u << PS_DROPPED);
     if (hasBonded_ && withBonded) mask |= (1u << PS_EBOND) | (1u << PS_EANGLE);
@@ -1088,9 +1088,10 @@ void Engine::run_steps(int nsteps)
     // wall crossings when they happen, and check every atom's displacement; should one ever leave the slack (the interval is sized with a factor 2 to
     // spare from the largest step seen), the pair kernels reach one cell further until the next sort - slower, still exact.  The first step of
     // every call sorts (the deferred half-kick is re-armed by the scan).
-    // One GPU with pair lists: a sort interval runs on from the previous call when nothing has touched the state since (the lists are those of the arrays
-    // as they stand); the plain steps that finish it are launched one by one, whole cycles are replayed as graphs after that.
-    const bool carryOn = lazyOn_ && nranks_ == 1 && listsOn_ && listsValid_ && lazyK_ > 1 && sinceSort_ < (1 << 29) && pair_variant() == 2;
+    // With pair lists a sort interval runs on from the previous call when nothing has touched the state since (the lists are those of the arrays as they
+    // stand; slab ranks: when all ranks agreed at the end of the previous call that they can - a rebuild step carries the full exchange, so they must
+    // take it together); the plain steps that finish it are launched one by one, whole cycles are replayed as graphs after that.
+    const bool carryOn = lazyOn_ && (nranks_ == 1 || carryAgreed_) && listsOn_ && listsValid_ && lazyK_ > 1 && sinceSort_ < (1 << 29) && pair_variant() == 2;
     if (!carryOn) sinceSort_ = 1 << 30;
     preIntegrated_ = false;
     while (carryOn && done < nsteps && sinceSort_ < lazyK_ - 1) { stepsLeftInRun_ = nsteps - 1 - done; launch_step_kernels(); done++; }
@@ -1119,7 +1120,7 @@ void Engine::run_steps(int nsteps)
 void Engine::prepare_next_call()
 {
     if (!lazyOn_ || !lazyMeasured_) return;
-    if (nranks_ == 1 && listsOn_ && lazyK_ > 1 && !listsValid_ && sinceSort_ == 0 && pair_variant() == 2)
+    if (listsOn_ && lazyK_ > 1 && !listsValid_ && sinceSort_ == 0 && pair_variant() == 2)
     {
         PairLists pl;
         pl.cand = dCandList_; pl.meta = dListMeta_; pl.pairs = dPairList_; pl.laneCnt = dLaneCnt_; pl.noList = dNoList_;
@@ -1128,7 +1129,20 @@ void Engine::prepare_next_call()
         launch_build_lists(P_, S_, dPots_, cur(), dCounts_, dCellStart_, stream_, PairRange(), pl);
         check_launch("list building");
         sync();
+        if (nranks_ > 1)
+        {   // the plain steps' coordinate exchange needs to know where the boundary layers sit; with interval 1 nobody had asked (k_rank_gather left it ready)
+            int32_t h[5];
+            HIP_CHECK(hipMemcpy(h, dHaloInfo_, sizeof(h), hipMemcpyDeviceToHost));
+            halo_[0] = h[2]; halo_[1] = h[0]; halo_[2] = h[1]; halo_[3] = h[3]; halo_[4] = h[4];
+            haloInfoPending_ = false;
+        }
         listsValid_ = true;
+    }
+    if (nranks_ > 1)
+    {   // can every rank open the next call with plain steps?
+        double cannot = (listsOn_ && listsValid_ && lazyK_ > 1 && pair_variant() == 2) ? 0.0 : 1.0;
+        xch_->allreduce_sum(&cannot, 1, stream_);
+        carryAgreed_ = cannot == 0.0;
     }
     if (can_graph()) (void)graph_for_state(graph_cycle());
 }
@@ -1357,7 +1371,7 @@ int Engine::cell_table(int32_t dims[3], int32_t* cellStart, int capCells, int32_
 void Engine::set_state(const aztot_state& in)
 {
     sync();
-    sinceSort_ = 1 << 30; listsValid_ = false;       // the next call rebuilds the cells
+    sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false;       // the next call rebuilds the cells
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
     const int n = c.ownedEnd - c.ownedBegin;
