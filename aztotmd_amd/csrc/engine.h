@@ -182,6 +182,11 @@ private:
     // a sort interval may run on from one aztot_step call into the next (one GPU, pair lists): the lists recorded at the last rebuild are those of the
     // arrays as they stand; set_state / aztot_forces end that
     bool listsValid_ = false;
+    // slab ranks: how many cells the last list build left without a list, copied to pinned memory behind the build; once the copy has landed and says
+    // "none", the clean-up launches of the interval are skipped (a slab rank cannot widen its stencil, so the clean-up launch has nothing else to do there)
+    int32_t* hUnlisted_ = nullptr;
+    hipEvent_t evUnlisted_ = nullptr;
+    int unlistedState_ = 0;         // 0 unknown (copy in flight or never made), 1 known to be zero, 2 known to be non-zero
     bool carryAgreed_ = false;      // slab ranks: every rank can carry the interval on (decided together at the end of the previous call)
     void prepare_next_call();
 };

@@ -300,6 +300,10 @@ void Engine::release()
     if (evIntegrated_) (void)hipEventDestroy(evIntegrated_);
     if (evHalo_) (void)hipEventDestroy(evHalo_);
     evIntegrated_ = evHalo_ = nullptr;
+    if (evUnlisted_) (void)hipEventDestroy(evUnlisted_);
+    evUnlisted_ = nullptr;
+    if (hUnlisted_) (void)hipHostFree(hUnlisted_);
+    hUnlisted_ = nullptr;
     if (evHaloInfo_) (void)hipEventDestroy(evHaloInfo_);
     evHaloInfo_ = nullptr;
     if (hHalo_) (void)hipHostFree(hHalo_);
@@ -734,14 +738,29 @@ void Engine::launch_pair()
                 {   // (k_rank_gather has cleared the count of cells without a list)
                     timed("build_lists", [&] { launch_build_lists(Q, S_, dPots_, cur(), dCounts_, dCellStart_, stream_, PairRange(), pl); });
                     listsValid_ = true;
+                    unlistedState_ = 0;
+                    if (nranks_ > 1 && !capturing_)
+                    {
+                        if (!hUnlisted_)
+                        {
+                            HIP_CHECK(hipHostMalloc((void**)&hUnlisted_, sizeof(int32_t) * 4, hipHostMallocDefault));
+                            HIP_CHECK(hipEventCreateWithFlags(&evUnlisted_, hipEventDisableTiming));
+                        }
+                        HIP_CHECK(hipMemcpyAsync(hUnlisted_, dNoList_ + 2, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+                        HIP_CHECK(hipEventRecord(evUnlisted_, stream_));
+                    }
                 }
+                else if (nranks_ > 1 && unlistedState_ == 0 && hUnlisted_ && !capturing_ && hipEventQuery(evUnlisted_) == hipSuccess)
+                    unlistedState_ = (hUnlisted_[0] == 0) ? 1 : 2;
+                const bool skipCleanup = nranks_ > 1 && unlistedState_ == 1 && candMode_ == 2 && !capturing_;
                 NextStep nx;
                 nx.st = dStats_; nx.cnt = dCounts_; nx.R0 = ref_;
                 if (fuseNext_) { nx.xn = altXyz_[cur_][0]; nx.yn = altXyz_[cur_][1]; nx.zn = altXyz_[cur_][2]; }
                 else nx.pendingAfter = lazyKick_ ? 1 : -1;         // this step's second half-kick is owed to the next k_integrate1_bin (a call may open
                                                                     // with a plain step, where no scan re-arms the flag)
                 timed("pair_list", [&] { splitBlocks_ = launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, nx); });
-                timed("pair_cleanup", [&] { splitBlocks_ += launch_pair_cleanup(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, nx); });
+                if (!skipCleanup)
+                    timed("pair_cleanup", [&] { splitBlocks_ += launch_pair_cleanup(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, nx); });
                 if (fuseNext_)
                 {   // the next step's positions are in the other set of coordinate arrays now
                     AtomArrays& A = cur();
@@ -1129,6 +1148,11 @@ void Engine::prepare_next_call()
         launch_build_lists(P_, S_, dPots_, cur(), dCounts_, dCellStart_, stream_, PairRange(), pl);
         check_launch("list building");
         sync();
+        {
+            int32_t nl = 0;
+            HIP_CHECK(hipMemcpy(&nl, dNoList_ + 2, sizeof(nl), hipMemcpyDeviceToHost));
+            unlistedState_ = (nl == 0) ? 1 : 2;
+        }
         if (nranks_ > 1)
         {   // the plain steps' coordinate exchange needs to know where the boundary layers sit; with interval 1 nobody had asked (k_rank_gather left it ready)
             int32_t h[5];
