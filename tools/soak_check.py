@@ -1,7 +1,9 @@
+"""Long run cut into irregular aztot_step calls: the default engine (lazy re-sort, pair lists, fusion where it applies) against the every-step schedule.
+    python tools/soak_check.py [workload]"""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 from aztotmd_amd import api, inputs
-case = inputs.config("C4")
+case = inputs.config(sys.argv[1] if len(sys.argv) > 1 else "C4")
 m = api.Model.from_case(case)
 a = api.Engine(m, initial_forces=1)
 b = api.Engine(m, initial_forces=1, sort_every=1)
