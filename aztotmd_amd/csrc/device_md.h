@@ -148,6 +148,8 @@ enum PartialSlot
 struct DevStats
 {
     long long step;
+    long long stepAtSort;         // number of the last step that rebuilt the cells (k_integrate1_bin<1>): lets a launch derive the number of the step it
+                                  // belongs to from StepParams::cycleStep without reading a counter another thread of the same launch advances
     double engKin, engVdW, engCoul, engElecField, engTemp, engTot, engPot, temperature;
     double engBond, engAngle;     // exec_bondlist bonds.cpp:1218 / exec_anglelist angles.cpp:240
     double engCoulRec, engCoulConst;   // Ewald sum: reciprocal (engElec2) and constant (engElec1) parts; the same on every rank

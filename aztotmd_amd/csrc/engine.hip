@@ -952,12 +952,12 @@ void Engine::launch_step_kernels()
     // kernel's epilogue (fuseEpilogue_); large ones -> the next step's k_integrate1_bin (lazyKick_, see finish_steps)
     fuseNow_ = fuseEpilogue_;
     const int stepMode = (lazyOn_ && sinceSort_ < lazyK_ - 1) ? 2 : 1;
-    {   // does this step's pair kernel also open the next step?  Only if there is one before the host looks or the cycle ends, if it is a plain step,
-        // and if this step walks the lists (k_pair_list and its clean-up launch carry the epilogue)
-        const int sinceAfter = (stepMode == 2) ? sinceSort_ + 1 : 0;
-        const bool nextPlain = lazyOn_ && sinceAfter < lazyK_ - 1;
+    // is there a next step before the host looks or the cycle ends, and is it a plain one?
+    const int sinceAfter = (stepMode == 2) ? sinceSort_ + 1 : 0;
+    const bool nextPlain = lazyOn_ && sinceAfter < lazyK_ - 1 && stepsLeftInRun_ > 0;
+    {   // does this step's pair kernel also open the next step?  Only if this step walks the lists (k_pair_list and its clean-up launch carry the epilogue)
         const bool lists = listsOn_ && lazyOn_ && lazyK_ > 1 && pair_variant() == 2;
-        fuseNext_ = fuseNextOk_ && lists && nextPlain && stepsLeftInRun_ > 0;
+        fuseNext_ = fuseNextOk_ && lists && nextPlain;
     }
     sort_and_forces(stepMode);
     const bool fused = fuseNow_;                 // launch_pair drops the request if the tile kernel is not the one running
@@ -966,7 +966,18 @@ void Engine::launch_step_kernels()
     // radiative thermostat without equilibration scaling: nothing global happens between the second half-kick and the thermostat - one launch (debug bit
     // 4194304: two, as everywhere else)
     const bool kickAndPost = !fused && !lazyKick_ && !equil && P_.tstat == AZTOT_TSTAT_RADI && !(opt_.reserved[0] & 4194304);
-    if (kickAndPost)
+    // ... and when a plain step follows, the same launch opens it (k_boundary_radi; debug bit 33554432: no)
+    if (kickAndPost && nextPlain && !(opt_.reserved[0] & 33554432))
+    {
+        StepParams Q = P_;
+        Q.cycleStep = sinceSort_ + 1;              // of the step being opened
+        timed("boundary", [&] {
+            hipLaunchKernelGGL(k_boundary_radi, dim3(gridAtoms), dim3(kBlock), 0, stream_, Q, S_, cur(), dCounts_, dPartials_, maxBlocks_, dStats_, dPhotons_, dUvx_, dUvy_,
+                               dUvz_, ref_);
+        });
+        preIntegrated_ = true;
+    }
+    else if (kickAndPost)
         timed("integrate2_post", [&] {
             hipLaunchKernelGGL(k_integrate2_post, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal, dPartials_,
                                maxBlocks_, dStats_, dPhotons_, dUvx_, dUvy_, dUvz_);

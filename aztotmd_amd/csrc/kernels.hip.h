@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
     const int begin = cnt->ownedBegin, end = cnt->ownedEnd;
     const int i = begin + blockIdx.x * kBlock + threadIdx.x;
     const bool pendingKick = INTEGRATE && st->pendingKick != 0;   // written only by kernels that run between two launches of this one
-    if (INTEGRATE && blockIdx.x == 0 && threadIdx.x == 0) st->step += 1;   // the step in flight gets its 1-based number (main.cpp:92);
+    if (INTEGRATE && blockIdx.x == 0 && threadIdx.x == 0) { st->step += 1; if (STEPMODE == 1) st->stepAtSort = st->step; }   // the step in flight gets its 1-based number (main.cpp:92);
                                                                            // read only by the thermostat kernels at the end of the step
     double eField = 0.0, mom[6] = {0, 0, 0, 0, 0, 0}, cross[6] = {0, 0, 0, 0, 0, 0}, stepLen2 = 0.0;
     int anyCross = 0, myCell = 0, myLayer = 0, violated = 0;
@@ -975,14 +975,14 @@ __device__ __forceinline__ void angled_vector(const double v[3], double cos_phi,
 // radiate_photon3 :631-685); v comes in and goes out through registers, the atom's internal energy and radius through memory.  Returns the atom's U.
 __device__ __forceinline__ double post_tstat_atom(const StepParams& P, const SpecTable& S, const AtomArrays& A, const DevStats* __restrict__ st,
                                                   const double* __restrict__ photons, const double* __restrict__ uvx, const double* __restrict__ uvy,
-                                                  const double* __restrict__ uvz, int i, double& vx, double& vy, double& vz)
+                                                  const double* __restrict__ uvz, int i, double& vx, double& vy, double& vz, long long stepNumber = -1)
 {
     double uSum = 0.0;
     const double k = st->vscale;
     if (k != 1.0) { vx *= k; vy *= k; vz *= k; }
     if (P.tstat == 2)
     {
-        const uint64_t step = (uint64_t)st->step;
+        const uint64_t step = (uint64_t)(stepNumber >= 0 ? stepNumber : st->step);
         const uint64_t id = (uint64_t)A.id[i];
         const int tp = A.type[i];
         const double m = S.mass[tp];
@@ -1081,6 +1081,94 @@ __global__ __launch_bounds__(kBlock) void k_integrate2_post(StepParams P, SpecTa
     if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EKIN, 0.5 * s);
     s = block_sum(uSum, scratch);
     if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_ETEMP, s);
+}
+
+// The boundary between two plain steps of a lazy run with the radiative thermostat (no equilibration scaling), in one launch: what k_integrate2_post
+// does to close step t (second half-kick, kinetic energy, thermostat) and what k_integrate1_bin<2> does to open step t + 1 (first half-kick, drift, wall
+// counters, displacement check) - per atom, in that order, with the same operations, so the trajectory is bit-identical to the two launches.  P.cycleStep
+// is that of the step being OPENED; the number of the step being closed, which keys the thermostat's random draws, is derived from it and from
+// DevStats::stepAtSort (the counter itself is advanced by one thread of this launch and must not be read by the others).
+__global__ __launch_bounds__(kBlock) void k_boundary_radi(StepParams P, SpecTable S, AtomArrays A, Counts* __restrict__ cnt, double* __restrict__ partials, int maxBlocks,
+                                                          DevStats* st, const double* __restrict__ photons, const double* __restrict__ uvx,
+                                                          const double* __restrict__ uvy, const double* __restrict__ uvz, RefPos R0)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int begin = cnt->ownedBegin, end = cnt->ownedEnd;
+    const int i = begin + gid;
+    const long long closing = st->stepAtSort + (long long)(P.cycleStep - 1);
+    if (gid == 0) { st->pendingKick = 0; st->step = closing + 1; }
+    double roomLeft = -1.0;
+    if (P.pad2)
+        roomLeft = sqrt(P.lazySlack2) - (double)(P.cycleStep - 1) * sqrt(__longlong_as_double((long long)__hip_atomic_load(&cnt->cycMaxRun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    double kin = 0.0, uSum = 0.0, mom[6] = {0, 0, 0, 0, 0, 0}, cross[6] = {0, 0, 0, 0, 0, 0}, stepLen2 = 0.0;
+    int anyCross = 0, violated = 0;
+    if (i < end)
+    {
+        const int t = A.type[i];
+        const double rM = S.rMhdt[t], m = S.mass[t];
+        const double fx = A.fx[i], fy = A.fy[i], fz = A.fz[i];
+        // ---- close step t (k_integrate2_post)
+        double vx = A.vx[i] + rM * fx;
+        double vy = A.vy[i] + rM * fy;
+        double vz = A.vz[i] + rM * fz;
+        kin = (vx * vx + vy * vy + vz * vz) * m;
+        uSum = post_tstat_atom(P, S, A, st, photons, uvx, uvy, uvz, i, vx, vy, vz, closing);
+        // ---- open step t + 1 (k_integrate1_bin<2>; nothing is pending: the kick above was this step's)
+        double x = A.x[i], y = A.y[i], z = A.z[i];
+        vx += rM * fx;
+        vy += rM * fy;
+        vz += rM * fz;
+        const int ix0 = image_of(x, P.L[0], P.invL[0]), iy0 = image_of(y, P.L[1], P.invL[1]), iz0 = image_of(z, P.L[2], P.invL[2]);
+        double dx = 0.0, dy = 0.0, dz = 0.0;
+        if (!S.frozen[t]) { dx = vx * P.dt; dy = vy * P.dt; dz = vz * P.dt; x += dx; y += dy; z += dz; }
+        stepLen2 = dx * dx + dy * dy + dz * dz;
+        int c;
+        c = image_of(x, P.L[0], P.invL[0]) - ix0;
+        if (c < 0) { mom[0] = m * (-vx); cross[0] = 1; anyCross = 1; } else if (c > 0) { mom[1] = m * vx; cross[1] = 1; anyCross = 1; }
+        c = image_of(y, P.L[1], P.invL[1]) - iy0;
+        if (c < 0) { mom[2] = m * (-vy); cross[2] = 1; anyCross = 1; } else if (c > 0) { mom[3] = m * vy; cross[3] = 1; anyCross = 1; }
+        c = image_of(z, P.L[2], P.invL[2]) - iz0;
+        if (c < 0) { mom[4] = m * (-vz); cross[4] = 1; anyCross = 1; } else if (c > 0) { mom[5] = m * vz; cross[5] = 1; anyCross = 1; }
+        if (!(roomLeft > 0.0 && stepLen2 < roomLeft * roomLeft))
+        {
+            const double ex = x - R0.x[i], ey = y - R0.y[i], ez = z - R0.z[i];
+            if (ex * ex + ey * ey + ez * ez > P.lazySlack2) violated = 1;
+        }
+        if (anyCross)
+        {
+#pragma unroll
+            for (int d = 0; d < 6; d++) if (cross[d] != 0.0) atomicAdd(&st->specCross[t * 6 + d], 1ULL);
+        }
+        A.vx[i] = vx; A.vy[i] = vy; A.vz[i] = vz;
+        A.x[i] = x; A.y[i] = y; A.z[i] = z;
+    }
+    double s = block_sum(kin, scratch);
+    if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EKIN, 0.5 * s);
+    s = block_sum(uSum, scratch);
+    if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_ETEMP, s);
+    {
+        const double mx = block_max(stepLen2, scratch);
+        if (threadIdx.x == 0)
+        {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
+            if (bits > __hip_atomic_load(&cnt->maxStep2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cnt->maxStep2, bits);
+            if (P.pad2 && bits > __hip_atomic_load(&cnt->cycMaxRun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cnt->cycMaxRun, bits);
+        }
+        if (__syncthreads_or(violated) && threadIdx.x == 0)
+        {
+            if (cnt->lazyViolated == 0) cnt->lazyViolated = max(P.cycleStep, 1);
+            cnt->lazyViolatedEver = 1;
+        }
+    }
+    if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EFIELD, 0.0);
+    if (__syncthreads_or(anyCross))
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+        {
+            const double a = block_sum(mom[k], scratch), b = block_sum(cross[k], scratch);
+            if (threadIdx.x == 0 && b != 0.0) { add_partial(partials, maxBlocks, PS_MOM_XN + k, a); add_partial(partials, maxBlocks, PS_CNT_XN + k, b); }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -660,20 +660,25 @@ def test_sort_interval_runs_on_across_calls():
 
 def test_kick_and_radiative_thermostat_in_one_launch():
     """Radiative thermostat without equilibration scaling: k_integrate2 and k_post run as ONE launch (nothing global happens between the second half-kick and
-    the thermostat).  Same operations in the same order: bit-identical to the two-launch form (debug bit 4194304), per-atom internal energies and radii
-    included, and equal to the oracle."""
-    case = inputs.lj_case((6, 6, 6), a=5.6, seed=61, rc=7.0, cell_list=7.5, vel_T=150.0, T=150.0, tstat="radi", radii=[(2.73, 4.731, 0.2)])
+    the thermostat), and when a plain step follows, the same launch opens it (k_boundary_radi: first half-kick, drift, wall counters, displacement check).
+    Same operations in the same order: bit-identical to the two-launch form (debug bit 4194304) and to the form without the boundary kernel (33554432),
+    per-atom internal energies and radii included, and equal to the oracle."""
+    case = inputs.lj_case((8, 8, 8), a=5.6, seed=61, rc=7.5, cell_list=7.9, vel_T=60.0, T=60.0, tstat="radi", radii=[(2.73, 4.731, 0.2)])       # 5 cells per axis: the lazy re-sort engages
     a = engine(case, pair_variant=2)
     b = engine(case, pair_variant=2, debug=4194304)
+    c = engine(case, pair_variant=2, debug=33554432)      # one launch for kick + thermostat, but no k_boundary_radi (which also opens the next plain step)
     o = oracle.Oracle(case)
     o.forces(1)
-    for n in (3, 20, 1, 16):
-        a.step(n); b.step(n); o.step(n)
-    a.set_profile(1); a.reset_kernel_times(); a.step(2); b.step(2); o.step(2)
+    for n in (3, 20, 1, 16, 37):
+        a.step(n); b.step(n); c.step(n); o.step(n)
+    a.set_profile(1); a.reset_kernel_times(); a.step(4); b.step(4); c.step(4); o.step(4)
     kt = a.kernel_times()
-    assert "integrate2_post" in kt and "post_tstat" not in kt and "integrate2" not in kt, sorted(kt)
-    sa, sb, so = a.state(), b.state(), o.state()
+    assert a.stats()["sort_interval"] >= 8, a.stats()
+    assert "integrate2_post" in kt and "boundary" in kt and "post_tstat" not in kt and "integrate2" not in kt, sorted(kt)
+    assert kt["boundary"]["calls"] == 3 and kt["integrate2_post"]["calls"] == 1, kt       # the last step before the host looks is closed on its own
+    sa, sb, sc, so = a.state(), b.state(), c.state(), o.state()
     for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz", "U", "radius"):
+        assert np.array_equal(sa[k], sc[k]), (k, rel_err(sa[k], sc[k]))
         assert np.array_equal(sa[k], sb[k]), (k, rel_err(sa[k], sb[k]))
         ko = "rad" if k == "radius" else k
         assert rel_err(sa[k], so[ko]) < 1e-8, (k, rel_err(sa[k], so[ko]))
