@@ -263,7 +263,7 @@ class Engine:
     """Device state + step driver (reference: cudaMD + the loop body of main.cu:281-410)."""
 
     def __init__(self, model, device=0, initial_forces=1, center_box=0, seed=12345, pair_variant=0, cell_size=0.0, use_graph=1,
-                 profile=0, slab=None, debug=0, sort_every=0):
+                 profile=0, slab=None, debug=0, sort_every=0, split=0):
         """slab: None or dict(rank=, nranks=, rccl_id=bytes) or dict(rank=, nranks=, sendrecv=callable, allreduce=callable)."""
         L = lib()
         o = _Options()
@@ -272,6 +272,7 @@ class Engine:
         o.pair_variant, o.cell_size, o.use_graph, o.profile = pair_variant, cell_size, use_graph, profile
         o.reserved[0] = debug
         o.reserved[2] = sort_every          # 0: adaptive lazy re-sort (default), 1: rebuild the cells every step, n: at most every n-th step
+        o.reserved[3] = split               # staging kernel: waves per cell (0: the engine decides; 1, 2, 4, 8: forced - measurements)
         self.model = model
         self.N = int(model.query("n_atoms")[0])
         self.h = C.c_void_p()

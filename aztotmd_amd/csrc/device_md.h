@@ -95,6 +95,18 @@ struct EwaldTables
     double scale, scale2;            // elec.cpp:380-381
 };
 
+// Few cells, wide stencils (case study 2: 4 000 atoms on 2.7 A cells, 7^3 = 343 stencil cells, five tiles' worth of candidates per cell): one wave per
+// cell leaves most of the chip idle and makes every wave long.  The stencil's (x, y) columns are then dealt to `n` waves per cell (a power of two); every
+// wave writes its partial forces to scratch, and the last one to arrive (one atomic per wave) adds them up IN FIXED ORDER and finishes the atoms - no
+// floating-point atomics, bit-reproducible.
+struct SplitArgs
+{
+    int n = 1;                                   // waves per cell
+    double *fx = nullptr, *fy = nullptr, *fz = nullptr;   // [n][capacity]: partial forces by sub-wave and atom
+    int32_t* arrived = nullptr;                  // [nCell]: sub-waves that have delivered (left at zero by the last one)
+    int capacity = 0;
+};
+
 // uniform parameters of the step (kernel argument, by value)
 struct StepParams
 {

@@ -181,6 +181,7 @@ private:
     int stepsLeftInRun_ = 0;        // steps that follow the one being launched before the host looks / the cycle ends
     // a sort interval may run on from one aztot_step call into the next (one GPU, pair lists): the lists recorded at the last rebuild are those of the
     // arrays as they stand; set_state / aztot_forces end that
+    SplitArgs split_{};             // few cells, wide stencils: several waves per cell in the staging kernel (pair_tile.hip.h)
     bool listsValid_ = false;
     // slab ranks: how many cells the last list build left without a list, copied to pinned memory behind the build; once the copy has landed and says
     // "none", the clean-up launches of the interval are skipped (a slab rank cannot widen its stencil, so the clean-up launch has nothing else to do there)

@@ -358,7 +358,24 @@ void Engine::allocate()
     else capacity_ = N;
     nCellAlloc_ = P_.nCellLocal;
     // + 24: a split launch rounds each of its three runs up to 8 workgroups; the clean-up launches behind k_pair_list book into their own slots
-    pairBlocks_ = std::max(div_up(capacity_, kBlock), pair_tile_grid(P_) + 24 + 3 * pair_cleanup_grid(pair_tile_cells(P_)));
+    {   // few cells (less than half a residency of waves) and a stencil with columns to share out: several waves per cell in the staging kernel
+        const int cells = pair_tile_cells(P_);
+        int n = 1;
+        if (pair_tile_supported(P_) && !(opt_.reserved[0] & 67108864))
+            while (n < 8 && cells * n * 2 <= 4096 && n * 2 <= P_.nOff[0] * P_.nOff[1]) n *= 2;
+        if (n == 1 && pair_tile_supported(P_) && !(opt_.reserved[0] & 67108864))
+        {   // more cells than that, but a stencil that needs several tiles per cell (dense systems, small cells: expected candidates = density x volume
+            // within the cut-off of a cell): two waves per cell, each with half the columns and fewer tile flushes (measured: S40 -8 %, M4 -9 %; four: worse)
+            const double r = model_.rMax, a = P_.csz[0], b = P_.csz[1], c = P_.csz[2];
+            const double vol = a * b * c + 2.0 * r * (a * b + b * c + c * a) + 3.14159265358979 * r * r * (a + b + c) + 4.18879020478639 * r * r * r;
+            const double density = (double)model_.nAt / (model_.L[0] * model_.L[1] * model_.L[2]);
+            if (density * vol > 1.15 * kTileCap && P_.nOff[0] * P_.nOff[1] >= 2) n = 2;
+        }
+        if (opt_.reserved[3] == 1 || opt_.reserved[3] == 2 || opt_.reserved[3] == 4 || opt_.reserved[3] == 8) n = opt_.reserved[3];      // measurements: forced
+        split_.n = n;
+        split_.capacity = capacity_;
+    }
+    pairBlocks_ = std::max(div_up(capacity_, kBlock), pair_tile_grid(P_) * split_.n + 24 + 3 * pair_cleanup_grid(pair_tile_cells(P_)));
     maxBlocks_ = std::max(div_up(capacity_, kBlock), pairBlocks_) + 1;
     auto alloc = [&](size_t bytes) { void* p = nullptr; HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16))); allocs_.push_back(p); return p; };
     const size_t nd = sizeof(double) * (size_t)capacity_, ni = sizeof(int32_t) * (size_t)capacity_;
@@ -385,6 +402,13 @@ void Engine::allocate()
         zero.vscale = 1.0;          // "no scaling"; only k_scale_decision ever changes it
         zero.vscaleBegin = 1.0;
         HIP_CHECK(hipMemcpy(dStats_, &zero, sizeof(DevStats), hipMemcpyHostToDevice));
+    }
+    if (split_.n > 1)
+    {
+        const size_t nb = sizeof(double) * (size_t)split_.n * capacity_;
+        split_.fx = (double*)alloc(nb); split_.fy = (double*)alloc(nb); split_.fz = (double*)alloc(nb);
+        split_.arrived = (int32_t*)alloc(sizeof(int32_t) * (size_t)P_.nCellLocal);
+        HIP_CHECK(hipMemsetAsync(split_.arrived, 0, sizeof(int32_t) * (size_t)P_.nCellLocal, stream_));
     }
     dCounts_ = (Counts*)alloc(sizeof(Counts));
     dChunkTot_ = (int32_t*)alloc(sizeof(int32_t) * (size_t)(div_up(nCellAlloc_, kScanChunk) + 1));
@@ -715,8 +739,8 @@ void Engine::launch_pair()
                 }
                 else
                 {
-                    launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, r);
-                    nb += pair_range_grid(r.n);
+                    launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, r, PairLists(), 0, NextStep(), split_);
+                    nb += pair_range_grid(r.n) * split_.n;
                 }
             };
             timed(lists ? "pair_list" : "pair_tile", [&] {
@@ -769,7 +793,7 @@ void Engine::launch_pair()
                 }
             }
             else
-                timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, 0); });
+                timed("pair_tile", [&] { launch_pair_tile(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, 0, NextStep(), split_); });
         }
     }
     else
@@ -778,7 +802,7 @@ void Engine::launch_pair()
                                dCellOfSorted_, dPartials_, maxBlocks_);
         });
     if (variant < 2) fuseNow_ = false;           // only the tile kernels have the fused epilogue (cannot happen: see the constructor)
-    pairBlocksUsed_ = (variant == 3) ? pair_quad_grid(P_) : (variant == 2) ? (splitBlocks_ ? splitBlocks_ : pair_tile_grid(P_)) : div_up(capacity_, kBlock);
+    pairBlocksUsed_ = (variant == 3) ? pair_quad_grid(P_) : (variant == 2) ? (splitBlocks_ ? splitBlocks_ : pair_tile_grid(P_) * split_.n) : div_up(capacity_, kBlock);
 }
 
 // slab ranks: where the boundary layers sit in the sorted arrays, as read back behind the last sort

@@ -526,7 +526,7 @@ template <int MODE, int VDW, bool CLEANUP, bool BUILD = false>
 __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase,
-                                                     PairLists L, NextStep N)
+                                                     PairLists L, NextStep N, SplitArgs Z)
 {
     constexpr bool REC = BUILD;
     constexpr bool onlyUnlisted = CLEANUP;           // (a template parameter: with the strided loop of the clean-up launch in it the full launch lost 7 %)
@@ -583,7 +583,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
     // has exactly one cell; the clean-up launch (a few workgroups that stride over all cells) takes those without a list - or, after a slack violation, all
     bool cleanupIdle = false;
     if (onlyUnlisted && !widened) cleanupIdle = L.noList[2] == 0;       // the last recording left no cell without a list: nothing to clean up
-    for (int rowBase = (int)(blockIdx.x >> 3); rowBase < per && !cleanupIdle; rowBase += CLEANUP ? kWave * rowStep : per)
+    const int nSplit = (CLEANUP || BUILD) ? 1 : Z.n;
+    const int sub = (int)(blockIdx.x >> 3) & (nSplit - 1);           // which share of the stencil's columns this wave takes (all shares of a cell on one XCD)
+    for (int rowBase = (int)(blockIdx.x >> 3) / nSplit; rowBase < per && !cleanupIdle; rowBase += CLEANUP ? kWave * rowStep : per)
     {
     unsigned long long todo = 1ULL;                                  // full launch: this workgroup's one cell
     if (CLEANUP)
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                     if (ny < 0) { ny += ncy; cys = 0; } else if (ny >= ncy) { ny -= ncy; cys = 2; }
                     const int zlo = cz - P.hw[2], zhi = cz + P.hw[2];
                     int zs, ze, czs = 1;
-                    bool have = sg < nSegTot;
+                    bool have = sg < nSegTot && (col & (nSplit - 1)) == sub;
                     if (seg == 0) { zs = max(zlo, 0); ze = min(zhi, ncz - 1); }
                     else if (seg == 1) { have = have && zlo < 0; zs = zlo + ncz; ze = ncz - 1; czs = 0; }
                     else { have = have && zhi >= ncz; zs = 0; ze = zhi - ncz; czs = 2; }
@@ -904,7 +906,19 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                 acc.fy += __shfl_xor(acc.fy, o, kWave);
                 acc.fz += __shfl_xor(acc.fz, o, kWave);
             }
-            if (validI && slice == 0)
+            if (nSplit > 1)
+            {   // this wave saw a share of the stencil only: deliver the partial force (finished below by the last share to arrive)
+                if (validI && slice == 0)
+                {
+                    const size_t o = (size_t)sub * Z.capacity + myi;
+                    // (device-coherent stores and, below, loads: they bypass the caches that are not coherent between CUs / XCDs, so that no fence - which
+                    //  on this chip writes the whole L2 back: 40 us per wave - is needed around the arrival count)
+                    __hip_atomic_store(&Z.fx[o], acc.fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&Z.fy[o], acc.fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&Z.fz[o], acc.fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            else if (validI && slice == 0)
             {
                 double q = 0.0;
                 if (!kOneSpecies) q = S.charge[ti];
@@ -923,6 +937,40 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
                 }
             }
             eV += acc.eV; eC += acc.eC; dropped += acc.dropped;
+        }
+        if (nSplit > 1)
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial forces above have reached the coherent level before the count goes up
+            int before = 0;
+            if (lane == 0) before = atomicAdd(&Z.arrived[cell], 1);
+            before = __shfl(before, 0, kWave);
+            if (before == nSplit - 1)
+            {   // every share is in: add them up in the order of the shares, and finish the cell's atoms as the one-wave form does
+                if (lane == 0) __hip_atomic_store(&Z.arrived[cell], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = ib + lane; i < ie; i += kWave)
+                {
+                    double fx = 0.0, fy = 0.0, fz = 0.0;
+                    for (int q = 0; q < nSplit; q++)
+                    {
+                        const size_t o = (size_t)q * Z.capacity + i;
+                        fx += __hip_atomic_load(&Z.fx[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        fy += __hip_atomic_load(&Z.fy[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        fz += __hip_atomic_load(&Z.fz[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    int ti = 0;
+                    double qi = 0.0;
+                    if (!kOneSpecies) { ti = A.type[i]; qi = S.charge[ti]; }
+                    const double fxi = -qi * P.E[0] + fx, fyi = -qi * P.E[1] + fy, fzi = -qi * P.E[2] + fz;
+                    A.fx[i] = fxi; A.fy[i] = fyi; A.fz[i] = fzi;
+                    if (P.fuseKick)
+                    {
+                        const double rM = S.rMhdt[ti], m = S.mass[ti];
+                        const double vx = A.vx[i] + rM * fxi, vy = A.vy[i] + rM * fyi, vz = A.vz[i] + rM * fzi;
+                        A.vx[i] = vx; A.vy[i] = vy; A.vz[i] = vz;
+                        eK += (vx * vx + vy * vy + vz * vz) * m;
+                    }
+                }
+            }
         }
     }
     }   // batches of rows
@@ -960,16 +1008,16 @@ inline void pair_range_default(const StepParams& P, PairRange& R)
 // listMode 0: stage every cell ; 2: clean-up launch - a small grid that stages the cells without a list
 template <int MODE, int VDW>
 inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
-                                int maxBlocks, hipStream_t stream, PairRange R, PairLists L, int listMode, NextStep N)
+                                int maxBlocks, hipStream_t stream, PairRange R, PairLists L, int listMode, NextStep N, SplitArgs Z)
 {
     pair_range_default(P, R);
     if (R.n == 0) return;
     if (listMode == 2)
         hipLaunchKernelGGL((k_pair_tile<MODE, VDW, true>), dim3(pair_cleanup_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
-                           cnt, R.blockBase, L, N);
+                           cnt, R.blockBase, L, N, SplitArgs());
     else
-        hipLaunchKernelGGL((k_pair_tile<MODE, VDW, false>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
-                           cnt, R.blockBase, L, NextStep());
+        hipLaunchKernelGGL((k_pair_tile<MODE, VDW, false>), dim3(pair_range_grid(R.n) * Z.n), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials,
+                           maxBlocks, cnt, R.blockBase, L, NextStep(), Z);
 }
 
 // the step that rebuilds the cells: candidates and pair lists of every cell (no forces; k_pair_list follows)
@@ -979,7 +1027,7 @@ inline void launch_build_lists(const StepParams& P, const SpecTable& S, const De
     pair_range_default(P, R);
     if (R.n == 0) return;
     hipLaunchKernelGGL((k_pair_tile<1, 1, false, true>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, (double*)nullptr, 0, cnt,
-                       0, L, NextStep());
+                       0, L, NextStep(), SplitArgs());
 }
 
 // dispatch on the potential set.  P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs; 5 = a mix of
@@ -1005,10 +1053,10 @@ inline void launch_build_lists(const StepParams& P, const SpecTable& S, const De
 
 inline void launch_pair_tile(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
                              double* partials, int maxBlocks, hipStream_t stream, PairRange R = PairRange(), PairLists L = PairLists(), int listMode = 0,
-                             NextStep N = NextStep())
+                             NextStep N = NextStep(), SplitArgs Z = SplitArgs())
 {
     if (!L.cand) listMode = 0;
-    AZTOT_PAIR_DISPATCH(launch_pair_tile_as, P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, listMode, N);
+    AZTOT_PAIR_DISPATCH(launch_pair_tile_as, P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, listMode, N, Z);
 }
 
 }  // namespace aztot

@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--emulate-ranks", type=int, default=0, help="measurement aid: time rank 0 of an N-rank slab run on one GPU (loopback halo)")
     ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels (enables hipGraph replay)")
     ap.add_argument("--no-graph", action="store_true", help="A/B aid: launch every kernel eagerly instead of replaying captured cycles")
+    ap.add_argument("--split", type=int, default=0, help="A/B aid: waves per cell in the staging pair kernel (0: the engine decides)")
     return ap.parse_args()
 
 
@@ -141,7 +142,7 @@ def main():
     transport = "single GPU"
     try:
         eng = api.Engine(model, device=local_rank, initial_forces=1, pair_variant=a.pair_variant, cell_size=a.cell_size,
-                         use_graph=0 if a.no_graph else 1, profile=0, slab=slab, debug=a.debug, sort_every=a.sort_every)
+                         use_graph=0 if a.no_graph else 1, profile=0, slab=slab, debug=a.debug, sort_every=a.sort_every, split=a.split)
         if world > 1:
             transport = "RCCL send/recv over xGMI"
         if a.emulate_ranks > 1:
