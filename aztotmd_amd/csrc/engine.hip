@@ -719,6 +719,9 @@ void Engine::launch_pair()
     {
         StepParams Q = P_;
         Q.fuseKick = fuseNow_ ? 1 : 0;
+        // pair energies are looked at through the statistics of a call's last step only (finish_steps): the list kernel of every other step books none
+        // (debug bit 134217728: every step does).  Inside a graph the last step of the cycle is the one that may be the call's last
+        const bool wantEnergies = stepsLeftInRun_ == 0 || (opt_.reserved[0] & 134217728);
         PairLists pl;
         if (listsOn_) { pl.cand = dCandList_; pl.meta = dListMeta_; pl.pairs = dPairList_; pl.laneCnt = dLaneCnt_; pl.noList = dNoList_; }
         if (overlapHalo_)
@@ -734,7 +737,7 @@ void Engine::launch_pair()
                 r.blockBase = nb;
                 if (lists)
                 {
-                    nb += launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, r, pl);
+                    nb += launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, r, pl, NextStep(), wantEnergies);
                     nb += launch_pair_cleanup(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, r, pl);
                 }
                 else
@@ -782,7 +785,7 @@ void Engine::launch_pair()
                 if (fuseNext_) { nx.xn = altXyz_[cur_][0]; nx.yn = altXyz_[cur_][1]; nx.zn = altXyz_[cur_][2]; }
                 else nx.pendingAfter = lazyKick_ ? 1 : -1;         // this step's second half-kick is owed to the next k_integrate1_bin (a call may open
                                                                     // with a plain step, where no scan re-arms the flag)
-                timed("pair_list", [&] { splitBlocks_ = launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, nx); });
+                timed("pair_list", [&] { splitBlocks_ = launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, nx, wantEnergies); });
                 if (!skipCleanup)
                     timed("pair_cleanup", [&] { splitBlocks_ += launch_pair_cleanup(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, nx); });
                 if (fuseNext_)
@@ -1139,7 +1142,7 @@ void Engine::run_steps(int nsteps)
     // Lazy re-sort (one GPU): the reference rebuilds its cell list every step (main.cu:300-326); here a step re-sorts only every lazyK_-th time.  That is
     // exact as long as no atom is farther than (stencil reach - rc) / 2 from where it was when the cells were built: every pair inside rc is then still
     // found in the stencil of the cell the atoms were sorted into.  Plain steps leave slots, cells and buffers alone, keep coordinates unwrapped, count
-    // wall crossings when they happen, and check every atom's displacement; should one ever leave the slack (the interval is sized with a factor 2 to
+    // wall crossings when they happen, and check every atom's displacement; should one ever leave the slack (the interval is sized with a factor 1.5 to
     // spare from the largest step seen), the pair kernels reach one cell further until the next sort - slower, still exact.  The first step of
     // every call sorts (the deferred half-kick is re-armed by the scan).
     // With pair lists a sort interval runs on from the previous call when nothing has touched the state since (the lists are those of the arrays as they

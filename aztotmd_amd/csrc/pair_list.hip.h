@@ -19,7 +19,10 @@
 
 namespace aztot {
 
-template <int MODE, int VDW>
+// ENG = false: the launch books no energies (steps whose energies nobody can see: all but the last step of an aztot_step call - the statistics are those of
+// the last step, finish_steps; the reference prints them every `stat` steps, cuStat.cu:308-330).  Forces are the same instructions either way: the energy
+// terms feed nothing else, the compiler drops them and their two wave reductions (C4: 603 -> 540 vector instructions per cell).
+template <int MODE, int VDW, bool ENG>
 __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase, PairLists L,
@@ -202,25 +205,29 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
                 // next step's k_integrate1_bin<2>
                 const double rM = S.rMhdt[ti], m = S.mass[ti];
                 double vx = v0x + rM * fxi, vy = v0y + rM * fyi, vz = v0z + rM * fzi;
-                if (P.fuseKick) eK += (vx * vx + vy * vy + vz * vz) * m;
+                if (ENG && P.fuseKick) eK += (vx * vx + vy * vy + vz * vz) * m;     // (the kinetic energy too is looked at after a call's last step only)
                 if (N.xn) next_step_atom(P, S, N, myi, ti, xr, yr, zr, fxi, fyi, fzi, vx, vy, vz, r0x, r0y, r0z, nacc);
                 A.vx[myi] = vx; A.vy[myi] = vy; A.vz[myi] = vz;
             }
         }
-        eV = acc.eV; eC = acc.eC; dropped = acc.dropped;
+        if (ENG) { eV = acc.eV; eC = acc.eC; }
+        dropped = acc.dropped;
     }
     // (the reductions are ~14 vector instructions each: skipped where the sum is known to be zero)
-    eV = wave_sum(eV);
-    if (MODE != 1 && MODE != 4) eC = wave_sum(eC);
+    if (ENG) eV = wave_sum(eV);
+    if (ENG && MODE != 1 && MODE != 4) eC = wave_sum(eC);
     if (__any(dropped != 0.0)) dropped = wave_sum(dropped);
     if (lane == 0)
     {
         const size_t pb = (size_t)blockBase + blockIdx.x;
-        partials[(size_t)PS_EVDW * maxBlocks + pb] = eV;
-        partials[(size_t)PS_ECOUL * maxBlocks + pb] = eC;
+        if (ENG)
+        {
+            partials[(size_t)PS_EVDW * maxBlocks + pb] = eV;
+            partials[(size_t)PS_ECOUL * maxBlocks + pb] = eC;
+        }
         if (dropped != 0.0) partials[(size_t)PS_DROPPED * maxBlocks + pb] += dropped;
     }
-    if (P.fuseKick)
+    if (ENG && P.fuseKick)
     {
         eK = wave_sum(eK);
         if (lane == 0) partials[(size_t)PS_EKIN * maxBlocks + blockBase + blockIdx.x] = 0.5 * eK;
@@ -236,20 +243,24 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
 
 template <int MODE, int VDW>
 inline void launch_pair_list_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
-                                int maxBlocks, hipStream_t stream, PairRange R, PairLists L, NextStep N)
+                                int maxBlocks, hipStream_t stream, PairRange R, PairLists L, NextStep N, bool energies)
 {
-    hipLaunchKernelGGL((k_pair_list<MODE, VDW>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt,
-                       R.blockBase, L, N);
+    if (energies)
+        hipLaunchKernelGGL((k_pair_list<MODE, VDW, true>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
+                           cnt, R.blockBase, L, N);
+    else
+        hipLaunchKernelGGL((k_pair_list<MODE, VDW, false>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
+                           cnt, R.blockBase, L, N);
 }
 
 // a plain step: the list kernel for every cell (launch_pair_list), then the clean-up launch of the staging kernel for the cells that keep no list
 // (launch_pair_cleanup; it books into the partial-sum slots behind the list kernel's).  Each returns the number of partial-sum slots it uses.
 inline int launch_pair_list(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
-                            double* partials, int maxBlocks, hipStream_t stream, PairRange R, PairLists L, NextStep N = NextStep())
+                            double* partials, int maxBlocks, hipStream_t stream, PairRange R, PairLists L, NextStep N = NextStep(), bool energies = true)
 {
     pair_range_default(P, R);
     if (R.n == 0) return 0;
-    auto list = [&]() { AZTOT_PAIR_DISPATCH(launch_pair_list_as, P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, N); };
+    auto list = [&]() { AZTOT_PAIR_DISPATCH(launch_pair_list_as, P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, N, energies); };
     list();
     return pair_range_grid(R.n);
 }

@@ -136,7 +136,8 @@ typedef struct
                                     exercises the wider-stencil fallback, 16384: slab ranks run the coordinate exchange of plain steps on a second stream beside the interior cells' pair forces - measured slower,
                                     32768: no pair lists (the steps between two rebuilds stage every cell), 65536: pair lists capped at 14 iterations (part of a liquid's cells then goes through the
                                     clean-up launch), 131072 / 262144: next-step fusion off / on whatever the system size, 524288: plain steps check every atom against its reference position (no displacement bound),
-                                    2097152: list statistics on stderr with AZTOT_VERBOSE, 4194304: second half-kick and radiative thermostat as two launches, 8388608: hipGraph replay also above 500 000 atoms, 16777216: plain steps integrate one atom per thread, 33554432: thermostat runs close a step and open the next in two launches, 67108864: one wave per cell in the staging kernel whatever the system) - and one that is NOT
+                                    2097152: list statistics on stderr with AZTOT_VERBOSE, 4194304: second half-kick and radiative thermostat as two launches, 8388608: hipGraph replay also above 500 000 atoms, 16777216: plain steps integrate one atom per thread, 33554432: thermostat runs close a step and open the next in two launches, 67108864: one wave per cell in the staging kernel whatever the system,
+                                    134217728: the list kernel books pair energies on every step, not only on the last step of a call) - and one that is NOT
                                     result-preserving: 2048 = the pair kernel stages its tile and stops (phase timing only);
                                     [1]: 1 = loopback slab transport (one rank of N talks to itself: timing aid);
                                     [3]: waves per cell in the staging pair kernel, 1 / 2 / 4 / 8 forced (0, default: the engine decides - several where cells are few or stencils wide);

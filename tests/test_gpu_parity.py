@@ -615,6 +615,44 @@ def test_next_step_fused_into_the_pair_kernel(kind):
         assert rel_err(sa[k], so[k]) < 1e-8, (k, rel_err(sa[k], so[k]))
 
 
+@pytest.mark.parametrize("kind", ["lj", "lj_fennell", "buck_ewald", "surk"])
+def test_pair_energies_only_where_somebody_can_see_them(kind):
+    """The statistics of an aztot_step call are those of its last step (the reference prints energies every `stat` steps, cuStat.cu:308-330), so the
+    list kernel of every other step of the call books no pair energies (k_pair_list<.., ENG = false>).  Nothing observable may change: positions,
+    velocities and forces BIT-IDENTICAL to a run whose every step books them (debug bit 134217728), and the energies after every call equal to the last
+    bit (the last step runs the same instantiation in both), whatever the pattern of calls; both agree with the oracle."""
+    if kind == "lj":
+        case = inputs.lj_case((8, 8, 8), a=5.6, seed=61, rc=7.5, cell_list=7.9, vel_T=200.0)
+    elif kind == "lj_fennell":
+        case = inputs.lj_case((8, 8, 8), a=5.6, seed=62, rc=7.5, cell_list=7.9, vel_T=200.0, charges=(0.3, -0.3), elec="fenn", r_real=7.5, alpha=0.3)
+    elif kind == "buck_ewald":                # Buckingham table + real-space Ewald term (MODE 3) next to the reciprocal-space kernels
+        case = family_with_coulomb("buck", "ewald", n=8, seed=7)
+    else:                                     # one species, radius-dependent 'surk' potential with the radiative thermostat (MODE 4)
+        pos, box = inputs.fcc_positions((7, 7, 7), 5.8, 0.1, 16)
+        N = len(pos)
+        case = {"box": box.tolist(), "dt": 0.001, "species": [(39.9, 0.0)], "names": ["Ar"], "types": np.zeros(N, dtype=np.int32),
+                "vdw": [(0, 0, 7, 6.0, [75.0, 8.0, 1.0, 1.0])], "radii": [(2.73, 4.731, 0.2)], "x": pos[:, 0].copy(), "y": pos[:, 1].copy(),
+                "z": pos[:, 2].copy(), "vx": np.zeros(N), "vy": np.zeros(N), "vz": np.zeros(N), "T": 300.0, "tstat_type": 2,
+                "cell_list": 6.5, "use_clist": 1, "elec_type": 0}
+    pv = {} if kind == "surk" else dict(pair_variant=2)
+    a = engine(case, **pv)
+    b = engine(case, debug=134217728, **pv)
+    o = oracle.Oracle(case)
+    o.forces(1)
+    for n in (10, 1, 37, 2, 33, 5):
+        a.step(n); b.step(n); o.step(n)
+        sa, sb, sta, stb = a.state(), b.state(), a.stats(), b.stats()
+        for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+            assert np.array_equal(sa[k], sb[k]), (n, k, rel_err(sa[k], sb[k]))
+        for k in ("engVdW", "engCoul", "engKin", "engTot"):
+            assert sta[k] == stb[k], (n, k, sta[k], stb[k])
+    assert sta["pair_lists"] == 1 and sta["sort_interval"] > 1
+    so, sto = o.state(), o.stats()
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(sa[k], so[k]) < 1e-8, (k, rel_err(sa[k], so[k]))
+    assert abs(sta["engTot"] - sto["engTot"]) <= 1e-9 * abs(sto["engTot"])
+
+
 def test_sort_interval_runs_on_across_calls():
     """One GPU, pair lists: the interval between two rebuilds of the cell list does not end with an aztot_step call - 40 single-step calls rebuild the cells
     as rarely as one 40-step call does (counted through the kernel timers), the lists made at the last rebuild stay in force, and the trajectory is

@@ -55,6 +55,7 @@ if os.path.isdir(fp64_dir):
             shutil.copy(src, os.path.join(P, "%s_rocprofv3_pmc_%s" % (tag, f.replace("_summary", "_counters"))))
 tp = os.path.join(P, "pmc_traffic.json")
 rec = json.load(open(tp)) if os.path.exists(tp) else {}
+seen = {}        # several instantiations share a bench name (k_pair_list<.., ENG = true / false>): the one launched most often carries the run
 for r in rows:
     k = r["kernel"]
     # bench.py's names: k_pair_list -> pair_list ; k_pair_tile<MODE, VDW, CLEANUP, BUILD>: BUILD -> build_lists, CLEANUP -> pair_cleanup, else pair_tile
@@ -65,7 +66,8 @@ for r in rows:
         name = "build_lists" if (len(a) > 3 and a[3] == "true") else ("pair_cleanup" if (len(a) > 2 and a[2] == "true") else "pair_tile")
     else:
         name = "pair_atom" if k == "k_pair_atom" else None
-    if name:
+    if name and r["dispatches"] > seen.get(name, 0):
+        seen[name] = r["dispatches"]
         rec["%s:%s:%d" % (workload, name, ngpu)] = {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"], "fp64_flop_per_launch": flop.get(r["kernel"]), "round": tag, "kernel": r["kernel"],
                                                     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH doubled per MI355X_MICROARCH.md"}
 json.dump(rec, open(tp, "w"), indent=1)
