@@ -253,7 +253,7 @@ def main():
                 traffic = flop = None
                 rec = {}
                 tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if os.path.exists(tp):
+                if os.path.exists(tp) and a.emulate_ranks <= 1:        # (the counters were collected on the whole system: they say nothing about one rank's share)
                     try:
                         rec = json.load(open(tp)).get("%s:%s:%d" % (a.workload, pair_name, world)) or {}
                         traffic = rec.get("hbm_bytes_per_launch")
