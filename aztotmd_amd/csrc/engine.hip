@@ -195,6 +195,31 @@ void Engine::construct()
         if (opt_.reserved[0] & 512) uniform = false;      // debug bit 512: take the generic kernel
         P_.pad1 = uniform ? 2 : 0;
         P_.vdwFamily = uniform ? family : 0;
+        if (uniform && family == AZTOT_VDW_LJ)
+        {   // the same shortcut for the Lennard-Jones family with charges: |f| <= |f_LJ| + |f_Coulomb|, each held below 0.5e5 beyond its radius.  LJ part
+            // as above per species pair; Coulomb part (direct, Fennell, real-space Ewald alike): |f| <= |kqq| (1/r^3 + (2 alpha/sqrt pi)/r^2 + S2/r)
+            double r2 = 0.0;
+            bool ok = true;
+            for (const auto& p : m.pairpots)
+            {
+                if (p.type == 0) continue;
+                const double ratio = 3.0 * p.p2 / (0.5e5 * p.p1);
+                if (ratio > 0.0 && ratio < 1.0 && p.p2 / p.p1 < 0.5e5) r2 = std::max(r2, p.p1 * std::pow(ratio, 1.0 / 7.0)); else ok = false;
+            }
+            double qq = 0.0;
+            for (int a = 0; a < m.nSpec(); a++)
+                for (int b = 0; b < m.nSpec(); b++) qq = std::max(qq, std::fabs(m.species[a].charge * m.species[b].charge) * units::Fcoul_scale);
+            if (m.elec_type != AZTOT_ELEC_NONE && qq > 0.0)
+            {
+                const double a2 = (m.elec_type == AZTOT_ELEC_DIRECT) ? 0.0 : 2.0 * std::fabs(m.alpha) / std::sqrt(units::pi);
+                const double s2 = (m.elec_type == AZTOT_ELEC_FENNEL) ? std::fabs(m.el_scale2) : 0.0;
+                double r = 0.01;
+                while (r < 100.0 && qq * (1.0 / (r * r * r) + a2 / (r * r) + s2 / r) > 0.5e5) r *= 1.05;
+                if (r >= 100.0) ok = false;
+                r2 = std::max(r2, r * r);
+            }
+            if (ok) P_.ljDropR2 = 2.0 * r2;
+        }
         // kernel specialisation 4: ONE species with the radius-dependent surk potential and no electrostatics (case study 2)
         if (m.nSpec() == 1 && m.pairpots[0].type == AZTOT_VDW_SURK && m.pairpots[0].use_radii && m.elec_type == AZTOT_ELEC_NONE && !(opt_.reserved[0] & 512))
             P_.pad1 = 4;
@@ -1058,15 +1083,20 @@ void Engine::finish_steps()
 void Engine::step(int nsteps)
 {
     if (nsteps <= 0) return;
-    // the sort interval is re-evaluated every 256 steps of a long call (and once after the first 8 steps an engine ever makes, so that even a
-    // single call benefits): a stream synchronisation and a 48-byte read-back
+    // the sort interval is re-evaluated inside a long call after 8, 16, 32, ... steps and then every 256 (a run that starts from rest speeds up for
+    // a while: the looks are close together where that happens), and at the end of every call: a stream synchronisation and a 48-byte read-back
     int left = nsteps;
     while (left > 0)
     {
-        const int n = lazyOn_ ? std::min(left, lazyMeasured_ ? 256 : 8) : left;
+        const int n = lazyOn_ ? std::min(left, lazyWindow_) : left;
         run_steps(n);
         left -= n;
-        if (left > 0) { sync(); adapt_sort_interval(); }
+        if (left > 0)
+        {
+            sync();
+            adapt_sort_interval();
+            lazyWindow_ = std::min(256, 2 * lazyWindow_);
+        }
     }
     kickOwed_ = lazyKick_;          // set here, not in launch_step_kernels: a replayed graph does not pass through the host code
     finish_steps();
@@ -1211,7 +1241,8 @@ void Engine::prepare_next_call()
 
 // the largest step any atom made since the last look sizes the next calls' sort interval: K steps of that length use at most two thirds of the slack
 // (one GPU; a violation is handled exactly by the clean-up launch at the staging kernel's speed, so the margin is a performance choice: with half the
-// slack C4 ran at K = 16, with two thirds at K = 24-28, no violation in 2 000 steps) - a quarter on slab ranks, which cannot widen their stencil
+// slack C4 ran at K = 16, with two thirds at K = 24-28, no violation in 2 000 steps; every violation widens the margin for good - a system that heats up,
+// like the Born-Mayer-Huggins melt B3, would otherwise run into one after the other) - a quarter on slab ranks, which cannot widen their stencil
 void Engine::adapt_sort_interval()
 {
     Counts c;
@@ -1233,7 +1264,7 @@ void Engine::adapt_sort_interval()
         {
             const int32_t z = 0;
             HIP_CHECK(hipMemcpy(&dCounts_->lazyViolatedEver, &z, sizeof(z), hipMemcpyHostToDevice));
-            lazyK_ = 1; lazyMeasured_ = false; lazyViolations_++;
+            lazyK_ = 1; lazyMeasured_ = false; lazyWindow_ = 8; lazyViolations_++;
             throw std::runtime_error("lazy re-sort on slab ranks: an atom left its cell's slack between two sorts (the speeds grew more than fourfold within one "
                                      "interval); the forces of this call are not exact - restart from the last state with options.reserved[2] = 1");
         }
@@ -1271,23 +1302,32 @@ void Engine::adapt_sort_interval()
         }
         K = lazyCap_;
     }
-    else if (c.lazyViolatedEver)
+    else
     {
-        const int32_t z = 0;
-        HIP_CHECK(hipMemcpy(&dCounts_->lazyViolatedEver, &z, sizeof(z), hipMemcpyHostToDevice));
-        K = std::max(1, K / 2);
-        lazyViolations_++;
-    }
-    else if (c.maxStep2 != 0)
-    {
-        double ms2;
-        std::memcpy(&ms2, &c.maxStep2, sizeof(ms2));
-        const double len = std::sqrt(ms2);
-        const double raw = len > 0 ? lazySlack_ / ((nranks_ > 1 ? 4.0 : 1.5) * len) : 1e9;
-        if (std::getenv("AZTOT_VERBOSE")) std::fprintf(stderr, "aztot: longest step %.3e A, slack %.3e A: interval up to %.1f steps\n", len, lazySlack_, raw);
-        static const int allowed[] = {32, 28, 24, 20, 16, 14, 12, 10, 8, 6, 5, 4, 3, 2, 1};
-        K = 1;
-        for (int a : allowed) if (a <= lazyCap_ && (double)a <= raw) { K = a; break; }
+        const bool violated = c.lazyViolatedEver != 0;
+        if (violated)
+        {
+            const int32_t z = 0;
+            HIP_CHECK(hipMemcpy(&dCounts_->lazyViolatedEver, &z, sizeof(z), hipMemcpyHostToDevice));
+            lazyViolations_++;
+            lazyMargin_ = std::min(4.0, lazyMargin_ * (4.0 / 3.0));      // the speeds are growing: more room from now on (1.5 -> 2 -> 2.7 -> 3.6 -> 4)
+        }
+        int fromSpeed = -1;
+        if (c.maxStep2 != 0)
+        {
+            double ms2;
+            std::memcpy(&ms2, &c.maxStep2, sizeof(ms2));
+            const double len = std::sqrt(ms2);
+            const double raw = len > 0 ? lazySlack_ / ((nranks_ > 1 ? 4.0 : lazyMargin_) * len) : 1e9;
+            if (std::getenv("AZTOT_VERBOSE"))
+                std::fprintf(stderr, "aztot: longest step %.3e A, slack %.3e A, margin %.2f%s: interval up to %.1f steps\n", len, lazySlack_, lazyMargin_, violated ? ", violated" : "", raw);
+            static const int allowed[] = {32, 28, 24, 20, 16, 14, 12, 10, 8, 6, 5, 4, 3, 2, 1};
+            fromSpeed = 1;
+            for (int a : allowed) if (a <= lazyCap_ && (double)a <= raw) { fromSpeed = a; break; }
+        }
+        // after a violation: half the interval, or what the speeds seen now allow if that is less (a melt that heats up outruns halving)
+        if (violated) K = std::max(1, fromSpeed > 0 ? std::min(K / 2, fromSpeed) : K / 2);
+        else if (fromSpeed > 0) K = fromSpeed;
     }
     if (K != lazyK_) { lazyK_ = K; destroy_graphs(); graphCycle_ = 0; }
 }

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     __shared__ double txyz[3 * kTileLds];                            // candidate coordinates RELATIVE to the centre of the centre cell
     __shared__ uint8_t ttyp[!kOneSpecies ? kTileLds : 1];            // species ids (< 16)
     __shared__ double trad[kRadii ? kTileLds : 1];
-    __shared__ double pairTab[(MODE == 2 || MODE == 3) ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
+    __shared__ double pairTab[(MODE == 2 || MODE == 3 || MODE == 5) ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
 
     const int lane = threadIdx.x;
     const int per = (nCellsRun + 7) >> 3;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         const int ib = cellStart[cell], ie = cellStart[cell + 1];
         const double cc0 = (lx + P.cx0) * P.csz[0] + 0.5 * P.csz[0], cc1 = cy * P.csz[1] + 0.5 * P.csz[1], cc2 = cz * P.csz[2] + 0.5 * P.csz[2];
         const DevPot lj = pots[0];
-        if (MODE == 2 || MODE == 3)
+        if (MODE == 2 || MODE == 3 || MODE == 5)
         {
             const int np = P.nSpec * P.nSpec;
             if (lane < np)
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         PairAcc acc = {0, 0, 0, 0, 0, 0};
         int nDropHalf = 0;
         const double ljDropR2 = P.ljDropR2;
+        const PairHot hot = (MODE == 2 || MODE == 3 || MODE == 5) ? pair_hot_in_vgprs(P) : pair_hot(P);
         const char* const tb = (const char*)txyz;
         const int nChunks = (nIter + 7) >> 3;
         // software-pipelined: the candidate of iteration t + 1 is read from LDS before the potential of iteration t is evaluated (entries behind a lane's
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
                 {
                     const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
                     const double r2 = dx * dx + dy * dy + dz * dz;
-                    pair_body<MODE, VDW>(P, S, pots, lj, pairTab, true, dx, dy, dz, r2, ti, tj, radi, radj, ljDropR2, nDropHalf, acc);
+                    pair_body<MODE, VDW, true>(P, S, pots, lj, pairTab, true, dx, dy, dz, r2, ti, tj, radi, radj, ljDropR2, nDropHalf, acc, hot);
                 }
                 xj = xn; yj = yn; zj = zn; tj = tn; radj = radn;
             }

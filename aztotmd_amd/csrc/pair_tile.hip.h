@@ -89,10 +89,24 @@ constexpr int kListStride16 = kListIters * kWave;   // uint16 entries per cell
 // One pair visit of the specialised tile kernels: potential + electrostatics of the pair (i, candidate) at separation (dx, dy, dz), r2 = |d|^2.
 // `live` = the lane really has a candidate (only the unmasked Coulomb forms of tile_passes pass false).  Shared by the staging kernel below and
 // by the pair-list kernel (pair_list.hip.h), so both evaluate a pair with exactly the same operations.
-template <int MODE, int VDW>
+// The two wave-uniform numbers the table-driven bodies need in every visit.  The list kernel keeps them in VECTOR registers (pair_hot_in_vgprs): with the 31
+// polynomial coefficients of exp and erfc in scalar registers the compiler otherwise re-loads them from the kernel arguments inside the pair loop, and the
+// s_waitcnt lgkmcnt(0) that follows also waits for the LDS reads of the next candidate issued just before - the software pipelining was gone.
+struct PairHot { double r2Max, alpha; };
+__device__ __forceinline__ PairHot pair_hot(const StepParams& P) { return PairHot{P.r2Max, P.alpha}; }
+__device__ __forceinline__ PairHot pair_hot_in_vgprs(const StepParams& P)
+{
+    PairHot h{P.r2Max, P.alpha};
+    asm volatile("" : "+v"(h.r2Max), "+v"(h.alpha));
+    return h;
+}
+
+// MASKED (list kernel: nearly every entry of a list is inside the cut-off): pairs outside the cut-off leave through the EXEC mask instead of being carried
+// along with r^2 = 1e300 and multiplied away - four selects less per visit, same arithmetic for the pairs that count.
+template <int MODE, int VDW, bool MASKED = false>
 __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots, const DevPot& lj, const double* pairTab,
                                           bool live, double dx, double dy, double dz, double r2, int ti, int tj, double radi, double radj, double ljDropR2,
-                                          int& nDropHalf, PairAcc& ra)
+                                          int& nDropHalf, PairAcc& ra, const PairHot& H)
 {
     if (MODE == 1)
     {   // fer_lj vdw.cpp:16-26 ; pair_inter integrators.cpp:139-185.  The atom itself (r2 == 0 exactly: its own
@@ -140,22 +154,26 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
     {   // one potential family for every species pair (VDW: 1 lnjs, 2 buck, 3 p746, 4 bmhs - fer_* of vdw.cpp:16-157), electrostatics
         // none, direct, Fennell/DSF (fennel elec.cpp:430-444) or the real-space Ewald term; parameters per species pair come from a
         // small LDS table {p0..p4, r2cut, kqq, aux}.  Branch-free: a pair outside its potential's cut-off is multiplied away.
+        // MODE 5 = MODE 2 with the electrostatics known when the kernel is compiled (Fennell/DSF): no wave-uniform branches inside the pair loop, which cost
+        // MODE 2 its instruction scheduling (every table read waited for on the spot) and, with three variants of the body alive, its scalar registers
         const double* pp = pairTab + (ti * P.nSpec + tj) * kPairTabStride;
-        const bool pairOk = live & (r2 > 0.0) & (r2 <= P.r2Max);
-        const double r2s = pairOk ? r2 : 1e300;
-        const bool coul = (MODE == 3) || (P.elec_type != 0);               // wave-uniform
+        const double tabP1 = pp[1], tabP2 = pp[2], tabCut = pp[5], tabKqq = pp[6];      // read whatever the pair turns out to be: the reads travel together
+        const bool pairOk = live & (r2 > 0.0) & (r2 <= H.r2Max);
+        if (MASKED && !pairOk) return;
+        const double r2s = (MASKED || pairOk) ? r2 : 1e300;
+        const bool coul = (MODE == 3) || (MODE == 5) || (P.elec_type != 0);               // wave-uniform
         const bool needR = coul || VDW != 1;
         const double ir = needR ? fast_rsqrt(r2s) : 0.0;
         const double r2i = needR ? ir * ir : fast_rcp(r2s);
         const double r = r2s * ir;
-        const bool vdwOk = r2s <= pp[5];
+        const bool vdwOk = r2s <= tabCut;
         double f;
         if (VDW == 1)
         {   // fer_lj vdw.cpp:16-26: p0 = 4 eps, p1 = sigma^2, p2 = 24 eps
-            const double sr2 = vdwOk ? pp[1] * r2i : 0.0;
+            const double sr2 = vdwOk ? tabP1 * r2i : 0.0;
             const double sr6 = sr2 * sr2 * sr2;
             ra.eV = fma(0.5 * pp[0], sr6 * (sr6 - 1.0), ra.eV);
-            f = pp[2] * r2i * sr6 * (2.0 * sr6 - 1.0);
+            f = tabP2 * r2i * sr6 * (2.0 * sr6 - 1.0);
         }
         else
         {
@@ -190,10 +208,10 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
             ra.eV = fma(0.5 * w, e, ra.eV);
             f *= w;
         }
-        if (MODE == 2 && P.elec_type == 3)
+        if (MODE == 5 || (MODE == 2 && P.elec_type == 3))
         {
-            const double kqq = pairOk ? pp[6] : 0.0;
-            const double ar = P.alpha * r;
+            const double kqq = (MASKED || pairOk) ? tabKqq : 0.0;
+            const double ar = H.alpha * r;
             const double ex = exp_nonpos(-ar * ar);
             const double erfcar = erfc_given_exp(ar, ex);
             ra.eC = fma(0.5 * kqq, erfcar * ir - P.el_scale + P.el_scale2 * (r - P.rReal), ra.eC);
@@ -201,8 +219,8 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
         }
         else if (MODE == 3)
         {   // real-space term of the Ewald sum: coul_iter elec.cpp:344-369 (real_ewald cuElec.cu:94-113)
-            const double kqq = pairOk ? pp[6] : 0.0;
-            const double ar = P.alpha * r;
+            const double kqq = (MASKED || pairOk) ? tabKqq : 0.0;
+            const double ar = H.alpha * r;
             const double ex = exp_nonpos(-ar * ar);
             const double erfcar = erfc_given_exp(ar, ex);
             ra.eC = fma(0.5 * kqq, erfcar * ir, ra.eC);
@@ -210,13 +228,19 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
         }
         else if (MODE == 2 && P.elec_type == 1)
         {   // direct_coul elec.cpp:415-428
-            const double kqq = pairOk ? pp[6] : 0.0;
+            const double kqq = (MASKED || pairOk) ? tabKqq : 0.0;
             ra.eC = fma(0.5 * kqq, ir, ra.eC);
             f = fma(kqq * ir, r2i, f);
         }
-        const bool tooBig = f * f > 1e10;                               // integrators.cpp:170-174: pair dropped
-        nDropHalf += tooBig ? 1 : 0;
-        const double fm = tooBig ? 0.0 : f;
+        // integrators.cpp:170-174: a pair with f^2 > 1e10 is dropped.  Lennard-Jones family: beyond ljDropR2 neither part of the force can get there
+        // (Engine::construct), so the exact test is a wave-uniform branch a liquid never takes; the other families test every pair
+        double fm = f;
+        if (VDW != 1 || __builtin_expect(__any(r2s < ljDropR2), 0))
+        {
+            const bool tooBig = f * f > 1e10;
+            nDropHalf += tooBig ? 1 : 0;
+            fm = tooBig ? 0.0 : f;
+        }
         ra.fx = fma(fm, dx, ra.fx); ra.fy = fma(fm, dy, ra.fy); ra.fz = fma(fm, dz, ra.fz);
     }
     else if (live && r2 > 0.0 && r2 <= P.r2Max)
@@ -342,9 +366,9 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
             const double r2 = dx * dx + dy * dy + dz * dz;
             int tj = 0;
             double radj = 0.0;
-            if (MODE == 0 || MODE == 2 || MODE == 3) tj = ttyp[k];
+            if (MODE == 0 || MODE == 2 || MODE == 3 || MODE == 5) tj = ttyp[k];
             if (MODE == 0 || MODE == 4) radj = trad[k];
-            pair_body<MODE, VDW>(P, S, pots, lj, pairTab, live, dx, dy, dz, r2, ti, tj, radi, radj, ljDropR2, nDropHalf, ra);
+            pair_body<MODE, VDW>(P, S, pots, lj, pairTab, live, dx, dy, dz, r2, ti, tj, radi, radj, ljDropR2, nDropHalf, ra, pair_hot(P));
             }
         } while (__any((cur | nxt | lst | ult) != 0u));
     }
@@ -523,7 +547,7 @@ template <int MODE, int VDW, bool CLEANUP, bool BUILD = false>
                       // CLEANUP: the clean-up launch behind k_pair_list - a small grid that strides over the cells and stages those without a list.
                       // BUILD (instantiated once, <1, 1, false, true>; the step that rebuilds the cells): no forces - stage every cell as usual, record the
                       // candidates its tile holds and make the pair lists from them; k_pair_list then computes that step's forces like any other's
-__global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
+__global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase,
                                                      PairLists L, NextStep N, SplitArgs Z)
@@ -549,7 +573,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
     double* const tz = txyz + 2 * kTileLds;
     __shared__ uint8_t ttyp[!kOneSpecies ? kTileLds : 1];               // species ids (< 16)
     __shared__ double trad[(MODE == 0 || MODE == 4) ? kTileLds : 1];
-    __shared__ double pairTab[(MODE == 2 || MODE == 3) ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
+    __shared__ double pairTab[(MODE == 2 || MODE == 3 || MODE == 5) ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
     __shared__ int32_t entJ[kWave], entN[kWave], entC[kWave];       // staging table: first atom, count (<= 64), image-shift code
 
     const int lane = threadIdx.x;
@@ -558,7 +582,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3) ? 3 : 1) void k_pai
     NextAcc nacc;
     next_acc_clear(nacc);
     const DevPot lj = pots[0];
-    if (MODE == 2 || MODE == 3)
+    if (MODE == 2 || MODE == 3 || MODE == 5)
     {
         const int np = P.nSpec * P.nSpec;
         if (lane < np)
@@ -1041,11 +1065,11 @@ inline void launch_build_lists(const StepParams& P, const SpecTable& S, const De
             const bool ew = P.elec_type == 2;                                                              \
             switch (P.vdwFamily)                                                                           \
             {                                                                                              \
-            case 1: if (ew) LAUNCH<3, 1>(__VA_ARGS__); else LAUNCH<2, 1>(__VA_ARGS__); return;             \
-            case 2: if (ew) LAUNCH<3, 2>(__VA_ARGS__); else LAUNCH<2, 2>(__VA_ARGS__); return;             \
-            case 3: if (ew) LAUNCH<3, 3>(__VA_ARGS__); else LAUNCH<2, 3>(__VA_ARGS__); return;             \
-            case 4: if (ew) LAUNCH<3, 4>(__VA_ARGS__); else LAUNCH<2, 4>(__VA_ARGS__); return;             \
-            case 5: if (ew) LAUNCH<3, 5>(__VA_ARGS__); else LAUNCH<2, 5>(__VA_ARGS__); return;             \
+            case 1: if (ew) LAUNCH<3, 1>(__VA_ARGS__); else if (P.elec_type == 3) LAUNCH<5, 1>(__VA_ARGS__); else LAUNCH<2, 1>(__VA_ARGS__); return; \
+            case 2: if (ew) LAUNCH<3, 2>(__VA_ARGS__); else if (P.elec_type == 3) LAUNCH<5, 2>(__VA_ARGS__); else LAUNCH<2, 2>(__VA_ARGS__); return; \
+            case 3: if (ew) LAUNCH<3, 3>(__VA_ARGS__); else if (P.elec_type == 3) LAUNCH<5, 3>(__VA_ARGS__); else LAUNCH<2, 3>(__VA_ARGS__); return; \
+            case 4: if (ew) LAUNCH<3, 4>(__VA_ARGS__); else if (P.elec_type == 3) LAUNCH<5, 4>(__VA_ARGS__); else LAUNCH<2, 4>(__VA_ARGS__); return; \
+            case 5: if (ew) LAUNCH<3, 5>(__VA_ARGS__); else if (P.elec_type == 3) LAUNCH<5, 5>(__VA_ARGS__); else LAUNCH<2, 5>(__VA_ARGS__); return; \
             }                                                                                              \
         }                                                                                                  \
         LAUNCH<0, 0>(__VA_ARGS__);                                                                         \
