@@ -56,7 +56,6 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     uint4 w = pl[0];
     uint4 w1 = pl[kWave];                                           // (the second chunk too: 16 iterations cover a liquid's cells, and a chunk asked for only
                                                                     //  8 iterations ahead arrives late)
-    const int cnt = L.laneCnt[(size_t)cell * kWave + lane];
     const int2 mx = ((const int2*)L.meta)[cell];                   // {list header, cell coordinates lx | cy << 10 | cz << 20}: one scalar load, no integer divisions
     int meta = mx.x;
     if (violated || cr >= nCellsRun) meta = -1;
@@ -139,6 +138,13 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
             else { put(0, ent[0], c0); put(1, ent[1], c1); put(2, ent[2], c2); put(3, ent[3], c3); }
         }
         const double xi = validI ? xr - cc0 : 1e30, yi = validI ? yr - cc1 : 1e30, zi = validI ? zr - cc2 : 1e30;
+        // the dummy candidate the unused list entries point at (kListDummy): far outside any cut-off, with a species and a radius the potentials can digest
+        if (lane == 0)
+        {
+            txyz[kTileLds - 1] = 1e30; txyz[2 * kTileLds - 1] = 1e30; txyz[3 * kTileLds - 1] = 1e30;
+            if (!kOneSpecies) ttyp[kTileLds - 1] = 0;
+            if (kRadii) trad[kTileLds - 1] = 1.0;
+        }
         __builtin_amdgcn_wave_barrier();
 
         // ---- every lane walks its list
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         const char* const tb = (const char*)txyz;
         const int nChunks = (nIter + 7) >> 3;
         // software-pipelined: the candidate of iteration t + 1 is read from LDS before the potential of iteration t is evaluated (entries behind a lane's
-        // last one are zero - the record clears the list buffer - so the read ahead is always a valid one)
+        // last one point at the dummy - the record fills the list buffer with kListDummy - so the read ahead is always a valid one)
         double xj, yj, zj, radj = 0.0;
         int tj = 0;
         auto fetch = [&](uint32_t ko, double& x, double& y, double& z, int& ty, double& rd) {
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
             if (!kOneSpecies) ty = ttyp[ko >> 3];
             if (kRadii) rd = *(const double*)((const char*)trad + ko);
         };
-        fetch(nIter > 0 ? (w.x & 0xFFFFu) : 0u, xj, yj, zj, tj, radj);
+        fetch(nIter > 0 ? (w.x & 0xFFFFu) : kListDummy, xj, yj, zj, tj, radj);
         for (int c = 0; c < nChunks; c++)
         {
             uint4 wn = w1;
@@ -174,8 +180,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
                 double xn, yn, zn, radn = 0.0;
                 int tn = 0;
                 fetch(kn, xn, yn, zn, tn, radn);
-                if (t < cnt)
-                {
+                {   // (no test of the lane's own entry count: behind its last entry a lane finds dummies)
                     const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
                     const double r2 = dx * dx + dy * dy + dz * dz;
                     pair_body<MODE, VDW, true>(P, S, pots, lj, pairTab, true, dx, dy, dz, r2, ti, tj, radi, radj, ljDropR2, nDropHalf, acc, hot);

@@ -85,6 +85,8 @@ constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-
 // wave reads a chunk as one coalesced 1 KiB load.
 constexpr int kListIters = 32;                       // iterations (entries per lane) a cell's list can hold; a cell that needs more keeps no list
 constexpr int kListStride16 = kListIters * kWave;   // uint16 entries per cell
+constexpr uint32_t kListDummy = (uint32_t)(kTileLds - 1) * 8u;          // entry of "no candidate": the last slot of the LDS tile (candidates fill slots < kTileCap)
+constexpr uint32_t kListDummy2 = kListDummy | (kListDummy << 16);
 
 // One pair visit of the specialised tile kernels: potential + electrostatics of the pair (i, candidate) at separation (dx, dy, dz), r2 = |d|^2.
 // `live` = the lane really has a candidate (only the unmasked Coulomb forms of tile_passes pass false).  Shared by the staging kernel below and
@@ -404,10 +406,11 @@ __device__ __forceinline__ void deal_hits(const double* tx, const double* ty, co
         for (int w = 0; w < 3 * NR; w++)
             if ((c >> 5) == w) mm[w] &= ~(0x80000000u >> (c & 31));
     }
-    // phase B: the tile is no longer needed - the list is assembled in its place.  Entries nobody writes read as offset 0 (k_pair_list reads one
-    // candidate ahead of the one it evaluates)
+    // phase B: the tile is no longer needed - the list is assembled in its place.  Entries nobody writes point at the tile's last slot, which never holds
+    // a candidate: k_pair_list parks a far-away dummy there, so a lane whose list is shorter than the wave's needs no test of its own - it walks on over
+    // dummies, which fail the cut-off test like any candidate outside rc (and the read one candidate ahead is always a valid one)
     __builtin_amdgcn_wave_barrier();
-    const uint4 zero4 = {0u, 0u, 0u, 0u};
+    const uint4 zero4 = {kListDummy2, kListDummy2, kListDummy2, kListDummy2};
     for (int q = lane; q < kListStride16 / 8; q += kWave) tlist[q] = zero4;
     __builtin_amdgcn_wave_barrier();
     uint16_t* const tl = (uint16_t*)tlist;
