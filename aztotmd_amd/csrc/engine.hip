@@ -1269,8 +1269,7 @@ void Engine::adapt_sort_interval()
                                      "interval); the forces of this call are not exact - restart from the last state with options.reserved[2] = 1");
         }
     }
-    const unsigned long long zero = 0;
-    HIP_CHECK(hipMemcpy(&dCounts_->maxStep2, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemsetAsync(&dCounts_->maxStep2, 0, sizeof(unsigned long long), stream_));      // (in stream order: no second round trip for the look)
     lazyMeasured_ = true;
     if (listsOn_)
     {   // cells that keep no list are staged by the small clean-up launch: fine for a few, slow for many (stencils wider than one tile, cells of more than
@@ -1286,7 +1285,7 @@ void Engine::adapt_sort_interval()
         }
         if (nl[1] > 0)
         {
-            HIP_CHECK(hipMemset(dNoList_, 0, sizeof(nl)));          // ([2] stays: it describes the lists in force)
+            HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(nl), stream_));          // ([2] stays: it describes the lists in force)
             if (std::getenv("AZTOT_VERBOSE")) std::fprintf(stderr, "aztot: lists recorded since the last look: %d cells, %d of them without a list\n", nl[1], nl[0]);
             if ((double)nl[0] > 0.02 * (double)nl[1] && !(opt_.reserved[0] & 65536)) { listsOn_ = false; destroy_graphs(); graphCycle_ = 0; }
         }
