@@ -63,9 +63,10 @@ class _Bonded(C.Structure):
 
 
 class _Options(C.Structure):
-    _fields_ = [("device", C.c_int32), ("initial_forces", C.c_int32), ("center_box", C.c_int32), ("seed", C.c_uint64),
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("initial_forces", C.c_int32), ("center_box", C.c_int32), ("seed", C.c_uint64),
                 ("pair_variant", C.c_int32), ("cell_size", C.c_double), ("use_graph", C.c_int32), ("profile", C.c_int32),
-                ("reserved", C.c_int32 * 8)]
+                ("sort_every", C.c_int32), ("skin", C.c_double), ("waves_per_cell", C.c_int32), ("energies_every_step", C.c_int32),
+                ("loopback_ranks", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class _Stats(C.Structure):
@@ -263,27 +264,43 @@ class Engine:
     """Device state + step driver (reference: cudaMD + the loop body of main.cu:281-410)."""
 
     def __init__(self, model, device=0, initial_forces=1, center_box=0, seed=12345, pair_variant=0, cell_size=0.0, use_graph=1,
-                 profile=0, slab=None, debug=0, sort_every=0, split=0):
-        """slab: None or dict(rank=, nranks=, rccl_id=bytes) or dict(rank=, nranks=, sendrecv=callable, allreduce=callable)."""
+                 profile=0, slab=None, debug=0, sort_every=0, split=0, skin=0.0, energies_every_step=0):
+        """slab: None or dict(rank=, nranks=, rccl_id=bytes) or dict(rank=, nranks=, sendrecv=callable, allreduce=callable).
+        debug: measurement / test switches (DebugBit in csrc/engine.h); they are not part of the ABI - the library reads them from the
+        environment variable AZTOT_DEBUG when the device handle is created, so it is set around that call here."""
         L = lib()
         o = _Options()
         L.aztot_default_options(C.byref(o))
         o.device, o.initial_forces, o.center_box, o.seed = device, initial_forces, center_box, seed
         o.pair_variant, o.cell_size, o.use_graph, o.profile = pair_variant, cell_size, use_graph, profile
-        o.reserved[0] = debug
-        o.reserved[2] = sort_every          # 0: adaptive lazy re-sort (default), 1: rebuild the cells every step, n: at most every n-th step
-        o.reserved[3] = split               # staging kernel: waves per cell (0: the engine decides; 1, 2, 4, 8: forced - measurements)
+        o.sort_every = sort_every           # 0: adaptive lazy re-sort (default), 1: rebuild the cells every step, n: at most every n-th step
+        o.skin = skin                       # Verlet skin in A (0: automatic, < 0: none)
+        o.waves_per_cell = split            # staging kernel: waves per cell (0: the engine decides; 1, 2, 4, 8: forced - measurements)
+        o.energies_every_step = energies_every_step
         self.model = model
         self.N = int(model.query("n_atoms")[0])
         self.h = C.c_void_p()
         self._cb = None
+        old_dbg = os.environ.get("AZTOT_DEBUG")
+        if debug:
+            os.environ["AZTOT_DEBUG"] = str(int(debug) | int(old_dbg or "0", 0))
+        try:
+            self._create(L, model, o, slab)
+        finally:
+            if debug:
+                if old_dbg is None:
+                    os.environ.pop("AZTOT_DEBUG", None)
+                else:
+                    os.environ["AZTOT_DEBUG"] = old_dbg
+
+    def _create(self, L, model, o, slab):
         if slab is None:
             _check(L.aztot_init_device(model.h, C.byref(o), C.byref(self.h)))
         else:
             idb = slab.get("rccl_id")
             if slab.get("loopback"):
                 # measurement aid: one rank of an N-rank decomposition exchanging with itself (see LoopbackExchanger)
-                o.reserved[1] = 1
+                o.loopback_ranks = 1
                 _check(L.aztot_init_device_slab(model.h, C.byref(o), slab["rank"], slab["nranks"], None, SENDRECV_FN(), ALLREDUCE_FN(), None,
                                                 C.byref(self.h)))
             elif idb is not None:

@@ -190,6 +190,7 @@ void aztot_default_options(aztot_options* opt)
 {
     if (!opt) return;
     std::memset(opt, 0, sizeof(*opt));
+    opt->struct_size = (uint32_t)sizeof(*opt);
     opt->device = 0;
     opt->initial_forces = 1;
     opt->center_box = 0;
@@ -198,6 +199,8 @@ void aztot_default_options(aztot_options* opt)
     opt->cell_size = 0.0;
     opt->use_graph = 1;
     opt->profile = 0;
+    opt->sort_every = 0;
+    opt->skin = 0.0;
 }
 
 static int init_device_common(const aztot_model* h, const aztot_options* opt, int rank, int nranks, const void* id_bytes,
@@ -206,7 +209,14 @@ static int init_device_common(const aztot_model* h, const aztot_options* opt, in
     if (!h || !out) return fail(AZTOT_ERR_ARG, "null argument");
     *out = nullptr;
     aztot_options o;
-    if (opt) o = *opt; else aztot_default_options(&o);
+    if (opt)
+    {
+        if (opt->struct_size != (uint32_t)sizeof(aztot_options))
+            return fail(AZTOT_ERR_ARG, "aztot_options.struct_size does not match this library (start from aztot_default_options)");
+        o = *opt;
+        for (int r : o.reserved) if (r != 0) return fail(AZTOT_ERR_ARG, "aztot_options.reserved must be zero");
+    }
+    else aztot_default_options(&o);
     return guarded([&] {
         Model m = h->m;
         finish_model(m, o.seed);
@@ -223,7 +233,7 @@ static int init_device_common(const aztot_model* h, const aztot_options* opt, in
                 md->xch.reset(new RcclExchanger(rank, nranks, id_bytes));
             }
             else if (sr && ar) md->xch.reset(new CallbackExchanger(sr, ar, ctx));
-            else if (!o.reserved[1]) throw std::runtime_error("slab: neither an RCCL id nor exchange callbacks were given");
+            else if (!o.loopback_ranks) throw std::runtime_error("slab: neither an RCCL id nor exchange callbacks were given");
         }
         md->eng.reset(new Engine(m, o, rank, nranks, md->xch.get()));
         *out = md.release();

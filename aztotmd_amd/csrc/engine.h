@@ -17,6 +17,7 @@
 namespace aztot {
 
 struct Counts;
+struct PairLists;
 
 struct KernelTimer
 {
@@ -28,6 +29,31 @@ struct KernelTimer
 }  // namespace aztot
 #include "exchange.h"
 namespace aztot {
+
+// Measurement switches, read once from the environment variable AZTOT_DEBUG (a bit mask) when an engine is created.  Every bit but DBG_STAGE_ONLY keeps the
+// results unchanged (up to summation order): they select between code paths for A/B timing and let the tests reach paths a normal run rarely takes.
+enum DebugBit : unsigned
+{
+    DBG_KICK_EVERY_STEP = 128,           // k_integrate2 launched every step
+    DBG_LARGE_KICK_PATH = 256,           // the deferred half-kick of large systems whatever the size
+    DBG_GENERIC_PAIR = 512,              // the generic (switch-based) pair body instead of a specialised mode
+    DBG_STAGE_ONLY = 2048,               // NOT result-preserving: the staging pair kernel stages its tile and stops (phase timing)
+    DBG_SLAB_GRAPH = 4096,               // hipGraph replay of a loopback slab rank
+    DBG_FIXED_INTERVAL = 8192,           // lazy re-sort at the fixed interval options.sort_every whatever the atoms' speed (exercises the wider-stencil fallback)
+    DBG_OVERLAP_HALO = 16384,            // slab ranks: coordinate exchange of plain steps on a second stream beside the interior cells' pair forces (measured slower)
+    DBG_NO_LISTS = 32768,                // no pair lists: the steps between two rebuilds stage every cell
+    DBG_SHORT_LISTS = 65536,             // pair lists capped at 14 iterations (part of a liquid's cells then goes through the clean-up launch)
+    DBG_NO_FUSE_NEXT = 131072,           // next-step fusion off ...
+    DBG_FUSE_NEXT = 262144,              // ... or on, whatever the system size
+    DBG_CHECK_EVERY_ATOM = 524288,       // plain steps check every atom against its reference position (no displacement bound)
+    DBG_LIST_STATS = 2097152,            // list statistics on stderr (with AZTOT_VERBOSE)
+    DBG_KICK_POST_SPLIT = 4194304,       // second half-kick and radiative thermostat as two launches
+    DBG_GRAPH_ALWAYS = 8388608,          // hipGraph replay also above 500 000 atoms
+    DBG_PLAIN_ONE_ATOM = 16777216,       // plain steps integrate one atom per thread
+    DBG_NO_BOUNDARY_RADI = 33554432,     // thermostat runs close a step and open the next in two launches
+    DBG_ONE_WAVE_PER_CELL = 67108864,    // one wave per cell in the staging kernel whatever the system
+    DBG_ENERGIES_EVERY_STEP = 134217728  // = options.energies_every_step
+};
 
 class Engine
 {
@@ -77,6 +103,7 @@ private:
 
     Model model_;
     aztot_options opt_;
+    unsigned debug_ = 0;            // AZTOT_DEBUG (DebugBit)
     StepParams P_{};
     SpecTable S_{};
     int rank_, nranks_;
@@ -123,7 +150,15 @@ private:
     uint32_t* dCandList_ = nullptr;
     int32_t* dListMeta_ = nullptr;
     uint16_t* dPairList_ = nullptr;
-    uint8_t* dLaneCnt_ = nullptr;
+    int candLds_ = 0, iterLds_ = 0; // what the LDS tiles of k_pair_list / k_build_lists are sized for (<= the capacities; from the largest cell recorded)
+    float4* dRel_ = nullptr;        // [capacity + 64] position relative to the own cell's centre (f32) + cell z index, written by the sort for the list builder
+    int candCap_ = 0, iterCap_ = 0; // capacities of the lists per cell (PairLists); grown when too many cells turn out not to fit
+    int listGrowths_ = 0;
+    size_t listLdsMax_ = 0;         // dynamic LDS this device grants a workgroup
+    void allocate_lists(int candCap, int iterCap);
+    void free_lists();
+    PairLists pair_lists() const;
+    double skinTarget_ = 0.0;       // the skin the cells were sized for (0: none)
     int32_t* dNoList_ = nullptr;    // [2]: cells recorded without / with a list since the host last looked
     bool listsOn_ = false;          // plain steps run k_pair_list (switched off when too many cells turn out to keep no list)
     int candMode_ = 0;              // for the pair launch in flight: 0 none, 1 record, 2 plain step of the lazy re-sort

@@ -31,6 +31,9 @@ void check_hip(hipError_t e, const char* what)
 namespace {
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 constexpr int kFuseKickMaxAtoms = 262144;
+constexpr int kLazyCapMax = 64;          // longest sort interval (steps)
+constexpr int kListCandMax = 1920;       // the LDS tile of k_pair_list holds candCap + 1 records of 32 B next to a 1 KiB table: below 64 KiB
+constexpr int kListIterMax = 248;
 }  // namespace
 
 template <typename F>
@@ -90,6 +93,29 @@ void Engine::choose_cells()
     const Model& m = model_;
     double size = opt_.cell_size > 0 ? opt_.cell_size : ((m.use_clist && m.desired_cell_size > 0) ? m.desired_cell_size : m.rMax);
     if (!(size > 0)) size = std::max(m.L[0], std::max(m.L[1], m.L[2]));
+    // Verlet skin (options.skin): the lazy re-sort keeps the cells for as long as no atom has moved farther than skin / 2, which needs a stencil that
+    // reaches rc + skin.  When the user asks for cells of about the cut-off (`cell_list 8.5` next to rc 8.5: the reference's split_cells then makes
+    // them L / floor(L / 8.5), cuCellList.cu:9-34 - whatever that overhangs the cut-off used to be all the slack there was: 0.05 A on the 361.305 A box,
+    // nothing at all on a box of 42 x 8.5 A) the cells are sized rc + skin instead; "edge >= the requested size" still holds.  Deliberately finer or
+    // coarser grids are left alone (their stencil reach is what it is).
+    skinTarget_ = 0.0;
+    const bool lazyWanted = opt_.sort_every != 1 && opt_.pair_variant != 3 && m.rMax > 0 && m.E[0] == 0.0 && m.E[1] == 0.0 && m.E[2] == 0.0 && opt_.skin >= 0.0;
+    if (lazyWanted)
+    {
+        const double skin = opt_.skin > 0.0 ? opt_.skin : std::min(0.5, std::max(0.15, 0.036 * m.rMax));
+        skinTarget_ = skin;
+        if (opt_.cell_size <= 0 && size >= 0.95 * m.rMax && size < m.rMax + skin)
+        {
+            bool ok = true;
+            for (int k = 0; k < 3; k++)
+            {   // (never at the price of the lazy schedule itself: it wants 5 cells per axis on one GPU, or of a slab split that the finer grid allows)
+                const int nFine = (int)std::floor(m.L[k] / size), nSkin = (int)std::floor(m.L[k] / (m.rMax + skin));
+                if (nSkin < 5 && nFine >= 5) ok = false;
+                if (k == 0 && nranks_ > 1 && nSkin / nranks_ < 2) ok = false;
+            }
+            if (ok) size = m.rMax + skin;
+        }
+    }
     for (int k = 0; k < 3; k++)
     {
         int n = (int)std::floor(m.L[k] / size);
@@ -149,7 +175,9 @@ void Engine::construct()
         HIP_CHECK(hipEventCreateWithFlags(&evHalo_, hipEventDisableTiming));
     }
     profile_ = opt_.profile != 0;
-    if (nranks_ > 1 && !xch_ && !opt_.reserved[1]) throw std::runtime_error("slab decomposition needs an exchanger");
+    if (const char* dbg = std::getenv("AZTOT_DEBUG")) debug_ = (unsigned)std::strtoul(dbg, nullptr, 0);
+    if (opt_.energies_every_step) debug_ |= DBG_ENERGIES_EVERY_STEP;
+    if (nranks_ > 1 && !xch_ && !opt_.loopback_ranks) throw std::runtime_error("slab decomposition needs an exchanger");
 
     const Model& m = model_;
     P_.nSpec = m.nSpec();
@@ -167,7 +195,7 @@ void Engine::construct()
     P_.numPi = 3.14159;         // cuTemp.cu:228
     P_.seed = opt_.seed;
     P_.rank = rank_; P_.nranks = nranks_;
-    P_.pad0 = opt_.reserved[0];
+    P_.pad0 = debug_;
     P_.use_radii = 0;
     for (const auto& p : m.pairpots) if (p.type && p.use_radii) P_.use_radii = 1;
     P_.single_lj = (m.nSpec() == 1 && m.pairpots[0].type == AZTOT_VDW_LJ && m.elec_type == AZTOT_ELEC_NONE) ? 1 : 0;
@@ -192,7 +220,7 @@ void Engine::construct()
         }
         if (family == 0) family = AZTOT_VDW_LJ;          // charges only: any family does, nothing is inside a VdW cut-off
         if ((m.elec_type == AZTOT_ELEC_FENNEL || m.elec_type == AZTOT_ELEC_EWALD) && m.alpha * m.rReal > 4.0) uniform = false;
-        if (opt_.reserved[0] & 512) uniform = false;      // debug bit 512: take the generic kernel
+        if (debug_ & 512) uniform = false;      // debug bit 512: take the generic kernel
         P_.pad1 = uniform ? 2 : 0;
         P_.vdwFamily = uniform ? family : 0;
         if (uniform && family == AZTOT_VDW_LJ)
@@ -221,7 +249,7 @@ void Engine::construct()
             if (ok) P_.ljDropR2 = 2.0 * r2;
         }
         // kernel specialisation 4: ONE species with the radius-dependent surk potential and no electrostatics (case study 2)
-        if (m.nSpec() == 1 && m.pairpots[0].type == AZTOT_VDW_SURK && m.pairpots[0].use_radii && m.elec_type == AZTOT_ELEC_NONE && !(opt_.reserved[0] & 512))
+        if (m.nSpec() == 1 && m.pairpots[0].type == AZTOT_VDW_SURK && m.pairpots[0].use_radii && m.elec_type == AZTOT_ELEC_NONE && !(debug_ & 512))
             P_.pad1 = 4;
     }
     std::memset(&S_, 0, sizeof(S_));
@@ -238,12 +266,12 @@ void Engine::construct()
     upload_ewald();
     {
         // who applies the second half-kick on plain NVE steps (nothing is added to the pair forces, nothing rescales velocities)
-        const bool plainNve = !(P_.nEq > 0) && P_.tstat == AZTOT_TSTAT_NONE && !hasBonded_ && !hasEwald_ && !(opt_.reserved[0] & 128);
+        const bool plainNve = !(P_.nEq > 0) && P_.tstat == AZTOT_TSTAT_NONE && !hasBonded_ && !hasEwald_ && !(debug_ & 128);
         const int variant = pair_variant();
         // small systems / slabs are bound by launch latency: the tile kernel's epilogue does it (one kernel less: C2 0.083 -> 0.063 ms).
         // On 1 M atoms that 13-lane read-modify-write of the velocities makes L2 write lines back several times (rocprofv3: 221 MB
         // instead of 63 + 76 MB per step) for no gain, so large systems fold it into the next step's streaming k_integrate1_bin.
-        fuseEpilogue_ = plainNve && variant >= 2 && capacity_ <= kFuseKickMaxAtoms && !(opt_.reserved[0] & 256);   // debug bit 256: large-system path
+        fuseEpilogue_ = plainNve && variant >= 2 && capacity_ <= kFuseKickMaxAtoms && !(debug_ & 256);   // debug bit 256: large-system path
         lazyKick_ = plainNve && !fuseEpilogue_;
         P_.pad2 = 0;
         // next-step fusion (NextStep, pair_tile.hip.h): plain NVE (nothing happens between the forces and the next half-kick; on slab ranks the coordinate
@@ -251,7 +279,7 @@ void Engine::construct()
         // pair lists; debug bit 131072 switches it off.  Up to ~500 000 atoms per GPU, where a step is bound by launch latency (measured: 40 000 atoms 0.0230 ->
         // 0.0199 ms/step; emulated slab ranks of 143 000 / 250 000 / 333 000 atoms -9 % / -5 % / -4 %): on 1 M atoms the 13-lane stores of the epilogue cost
         // the pair kernel exactly what the streaming k_integrate1_bin<2> costs on its own (111 + 31 -> 140 us); debug bit 262144 forces it on there
-        if (plainNve && listsOn_ && variant == 2 && !(opt_.reserved[0] & 131072) && (capacity_ <= 2 * kFuseKickMaxAtoms || (opt_.reserved[0] & 262144)))
+        if (plainNve && listsOn_ && variant == 2 && !(debug_ & 131072) && (capacity_ <= 2 * kFuseKickMaxAtoms || (debug_ & 262144)))
         {
             fuseNextOk_ = true;
             const size_t nd = sizeof(double) * (size_t)capacity_;
@@ -268,7 +296,7 @@ void Engine::construct()
     }
     // displacement bound instead of the per-atom check on plain steps: wherever k_integrate1_bin<2> opens every plain step (engines that fuse the next
     // step into the pair kernel keep the per-atom check there); debug bit 524288 switches it off
-    P_.pad2 = (lazyOn_ && !fuseNextOk_ && !(opt_.reserved[0] & 524288)) ? 1 : 0;
+    P_.pad2 = (lazyOn_ && !fuseNextOk_ && !(debug_ & 524288)) ? 1 : 0;
     if (nranks_ > 1 && !xch_)
     {   // options.reserved[1]: loopback measurement mode (see LoopbackExchanger)
         ownedXch_.reset(new LoopbackExchanger((P_.ncxLocal - 2 * P_.hw[0]) * P_.csz[0], P_.L[0], lay_.mig_offset(), lay_.halo_offset(),
@@ -322,6 +350,7 @@ void Engine::release()
     eventPool_.clear();
     for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
+    free_lists();
     if (evIntegrated_) (void)hipEventDestroy(evIntegrated_);
     if (evHalo_) (void)hipEventDestroy(evHalo_);
     evIntegrated_ = evHalo_ = nullptr;
@@ -386,9 +415,9 @@ void Engine::allocate()
     {   // few cells (less than half a residency of waves) and a stencil with columns to share out: several waves per cell in the staging kernel
         const int cells = pair_tile_cells(P_);
         int n = 1;
-        if (pair_tile_supported(P_) && !(opt_.reserved[0] & 67108864))
+        if (pair_tile_supported(P_) && !(debug_ & 67108864))
             while (n < 8 && cells * n * 2 <= 4096 && n * 2 <= P_.nOff[0] * P_.nOff[1]) n *= 2;
-        if (n == 1 && pair_tile_supported(P_) && !(opt_.reserved[0] & 67108864))
+        if (n == 1 && pair_tile_supported(P_) && !(debug_ & 67108864))
         {   // more cells than that, but a stencil that needs several tiles per cell (dense systems, small cells: expected candidates = density x volume
             // within the cut-off of a cell): two waves per cell, each with half the columns and fewer tile flushes (measured: S40 -8 %, M4 -9 %; four: worse)
             const double r = model_.rMax, a = P_.csz[0], b = P_.csz[1], c = P_.csz[2];
@@ -396,7 +425,7 @@ void Engine::allocate()
             const double density = (double)model_.nAt / (model_.L[0] * model_.L[1] * model_.L[2]);
             if (density * vol > 1.15 * kTileCap && P_.nOff[0] * P_.nOff[1] >= 2) n = 2;
         }
-        if (opt_.reserved[3] == 1 || opt_.reserved[3] == 2 || opt_.reserved[3] == 4 || opt_.reserved[3] == 8) n = opt_.reserved[3];      // measurements: forced
+        if (opt_.waves_per_cell == 1 || opt_.waves_per_cell == 2 || opt_.waves_per_cell == 4 || opt_.waves_per_cell == 8) n = opt_.waves_per_cell;      // measurements: forced
         split_.n = n;
         split_.capacity = capacity_;
     }
@@ -465,15 +494,16 @@ void Engine::allocate()
             slack = std::min(slack, 0.49 * (P_.hw[k] * P_.csz[k] - m.rMax));
             if (P_.nc[k] < 2 * (P_.hw[k] + 1) + 1) widenOk = false;
         }
-        const int sortEvery = opt_.reserved[2];                    // 0: adaptive, 1: every step (the reference's schedule), n: at most every n-th step
+        const int sortEvery = opt_.sort_every;                    // 0: adaptive, 1: every step (the reference's schedule), n: at most every n-th step
         // (a slab rank cannot widen its stencil - it holds hw ghost layers - so there a violation is an error and the interval keeps a factor 4 in hand)
         lazyOn_ = sortEvery != 1 && opt_.pair_variant != 3 && (widenOk || nranks_ > 1) && m.rMax > 0 && slack > 1e-3 && m.E[0] == 0.0 && m.E[1] == 0.0 &&
                   m.E[2] == 0.0 && pair_tile_supported(P_);
-        lazyCap_ = sortEvery > 1 ? std::min(sortEvery, 32) : 32;
-        if (lazyOn_ && (opt_.reserved[0] & 8192)) lazyK_ = lazyCap_;
-        // no more than 1.2 % of the cut-off: the tile kernels stage everything within rc + 2 slack of a cell, and a sort interval of 32 steps needs
-        // no more than that at liquid speeds (small cells would otherwise offer A of slack and pay for it in candidates: S40 +16 % pair time)
-        slack = std::min(slack, 0.012 * m.rMax);
+        lazyCap_ = sortEvery > 1 ? std::min(sortEvery, kLazyCapMax) : kLazyCapMax;
+        if (lazyOn_ && (debug_ & 8192)) lazyK_ = lazyCap_;
+        // The slack an atom may use is half the skin (both atoms of a pair move).  With a skin (options.skin >= 0) the cells were sized for it and the box
+        // may give a little more for free - taken up to a quarter above the target, beyond that it would only lengthen the lists; without one
+        // (options.skin < 0) it is capped at 1.2 % of the cut-off as in round 2.
+        slack = std::min(slack, skinTarget_ > 0.0 ? 0.5 * 1.25 * skinTarget_ : 0.012 * m.rMax);
         lazySlack_ = lazyOn_ ? slack : 0.0;
         P_.lazySlack2 = lazySlack_ * lazySlack_;
         const double rp = m.rMax + 2.0 * lazySlack_;
@@ -481,30 +511,28 @@ void Engine::allocate()
         if (lazyOn_)
         {
             ref_.x = (double*)alloc(nd); ref_.y = (double*)alloc(nd); ref_.z = (double*)alloc(nd);
-            if (capacity_ < (1 << 26) && !(opt_.reserved[0] & 32768))          // atom index + 6 bits of image code in 32 bits; debug 32768: no lists
+            if (capacity_ < (1 << 26) && !(debug_ & 32768))          // atom index + 6 bits of image code in 32 bits; debug 32768: no lists
             {
-                const size_t nc = (size_t)P_.nCellLocal;
-                dCandList_ = (uint32_t*)alloc(sizeof(uint32_t) * nc * kTileCap);
-                dListMeta_ = (int32_t*)alloc(sizeof(int32_t) * 2 * nc);
-                dPairList_ = (uint16_t*)alloc(sizeof(uint16_t) * nc * kListStride16);
-                dLaneCnt_ = (uint8_t*)alloc(nc * kWave);
-                dNoList_ = (int32_t*)alloc(sizeof(int32_t) * 8);
-                {   // header: -1 = no list ; second word: the cell's coordinates in the local grid (k_pair_list decodes them with shifts)
-                    if (P_.ncxLocal > 1023 || P_.nc[1] > 1023 || P_.nc[2] > 1023) throw std::runtime_error("more than 1023 cells along an axis");
-                    std::vector<int32_t> mx(2 * nc);
-                    const int ncy = P_.nc[1], ncz = P_.nc[2];
-                    for (size_t c = 0; c < nc; c++)
-                    {
-                        const int cz = (int)(c % ncz), cy = (int)((c / ncz) % ncy), lx = (int)(c / ((size_t)ncy * ncz));
-                        mx[2 * c] = -1; mx[2 * c + 1] = lx | (cy << 10) | (cz << 20);
-                    }
-                    HIP_CHECK(hipMemcpyAsync(dListMeta_, mx.data(), sizeof(int32_t) * 2 * nc, hipMemcpyHostToDevice, stream_));
-                    HIP_CHECK(hipStreamSynchronize(stream_));
-                }
-                HIP_CHECK(hipMemsetAsync(dCandList_, 0, sizeof(uint32_t) * nc * kTileCap, stream_));      // every entry is an atom index at all times
-                HIP_CHECK(hipMemsetAsync(dPairList_, 0, sizeof(uint16_t) * nc * kListStride16, stream_));   // every entry is a tile offset at all times (k_pair_list reads ahead)
-                HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(int32_t) * 8, stream_));
-                listsOn_ = true;
+                if (P_.ncxLocal > 1023 || P_.nc[1] > 1023 || P_.nc[2] > 1023) throw std::runtime_error("more than 1023 cells along an axis");
+                int devLds = 0;
+                HIP_CHECK(hipDeviceGetAttribute(&devLds, hipDeviceAttributeMaxSharedMemoryPerBlock, opt_.device));
+                listLdsMax_ = (size_t)std::max(devLds, 64 * 1024);
+                // capacities from the density: candidates = atoms within the list radius of a cell's box, iterations = pairs of a cell / 64 lanes, each
+                // with room for a liquid's fluctuations (+ 30 % / + 50 %); cells that need more keep no list, and the engine grows the lists when
+                // that happens to more than a few (adapt_sort_interval)
+                const double a = P_.csz[0], b = P_.csz[1], c = P_.csz[2], r = rp;
+                const double vol = a * b * c + 2.0 * r * (a * b + b * c + c * a) + 3.14159265358979 * r * r * (a + b + c) + 4.18879020478639 * r * r * r;
+                const double density = (double)m.nAt / (m.L[0] * m.L[1] * m.L[2]);
+                const double perCell = density * a * b * c, partners = density * 4.18879020478639 * r * r * r;
+                // (a cell's iterations are its atoms' partners divided by the slices each atom gets, NS = 64 / atoms: sized for a cell 60 % fuller than the mean)
+                const int nBig = std::min(kWave, (int)(1.6 * perCell) + 6);
+                int cand = (int)(density * vol * 1.5) + 64;
+                int iters = (int)(partners * 1.25 / list_slices(nBig)) + 4;
+                cand = std::max(kListMinCand, (cand + 63) & ~63);
+                iters = std::max(2 * kListMinIter, (iters + 7) & ~7);
+                if (const char* e = std::getenv("AZTOT_CAND_CAP")) cand = std::atoi(e);        // (experiments)
+                if (const char* e = std::getenv("AZTOT_ITER_CAP")) iters = std::atoi(e);
+                allocate_lists(cand, iters);
             }
         }
     }
@@ -523,6 +551,77 @@ void Engine::allocate()
     dPots_ = (DevPot*)alloc(sizeof(DevPot) * pots.size());
     HIP_CHECK(hipMemcpyAsync(dPots_, pots.data(), sizeof(DevPot) * pots.size(), hipMemcpyHostToDevice, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// Lists of the lazy re-sort (pair_list.hip.h): [nCell][candCap] candidates, [nCell][iterCap x 64] pair entries, headers.  Capacities are clipped to
+// what the LDS of k_pair_list / k_build_lists and the entry format allow.
+void Engine::allocate_lists(int candCap, int iterCap)
+{
+    free_lists();
+    candCap = std::min(candCap, kListCandMax);
+    iterCap = std::min(iterCap, kListIterMax);
+    PairLists probe;
+    probe.candCap = probe.candLds = candCap; probe.iterCap = probe.iterLds = iterCap; probe.recBytes = pair_list_rec_bytes(P_);
+    while (candCap > kListMinCand && (pair_list_lds_bytes(P_, probe) > listLdsMax_ || build_lists_lds_bytes(probe) > listLdsMax_))
+    {
+        candCap -= 64;
+        probe.candCap = probe.candLds = candCap;
+    }
+    while (iterCap > 2 * kListMinIter && build_lists_lds_bytes(probe) > listLdsMax_) { iterCap -= 8; probe.iterCap = probe.iterLds = iterCap; }
+    const size_t nc = (size_t)P_.nCellLocal;
+    auto alloc = [&](size_t bytes) { void* p = nullptr; HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16))); return p; };
+    dCandList_ = (uint32_t*)alloc(sizeof(uint32_t) * nc * candCap);
+    dListMeta_ = (int32_t*)alloc(sizeof(int32_t) * 2 * nc);
+    dPairList_ = (uint16_t*)alloc(sizeof(uint16_t) * nc * (size_t)iterCap * kWave);
+    dNoList_ = (int32_t*)alloc(sizeof(int32_t) * 16);
+    dRel_ = (float4*)alloc(sizeof(float4) * ((size_t)capacity_ + kWave));
+    HIP_CHECK(hipMemsetAsync(dRel_, 0, sizeof(float4) * ((size_t)capacity_ + kWave), stream_));
+    candCap_ = candCap; iterCap_ = iterCap;
+    candLds_ = candCap; iterLds_ = iterCap;          // (tightened once the builder has reported what the cells really hold: adapt_sort_interval)
+    {   // header: -1 = no list ; second word: the cell's coordinates in the local grid (the kernels decode them with shifts)
+        std::vector<int32_t> mx(2 * nc);
+        const int ncy = P_.nc[1], ncz = P_.nc[2];
+        for (size_t c = 0; c < nc; c++)
+        {
+            const int cz = (int)(c % ncz), cy = (int)((c / ncz) % ncy), lx = (int)(c / ((size_t)ncy * ncz));
+            mx[2 * c] = -1; mx[2 * c + 1] = lx | (cy << 10) | (cz << 20);
+        }
+        HIP_CHECK(hipMemcpyAsync(dListMeta_, mx.data(), sizeof(int32_t) * 2 * nc, hipMemcpyHostToDevice, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+    }
+    HIP_CHECK(hipMemsetAsync(dCandList_, 0, sizeof(uint32_t) * nc * candCap, stream_));      // every entry is an atom index at all times
+    HIP_CHECK(hipMemsetAsync(dPairList_, 0, sizeof(uint16_t) * nc * (size_t)iterCap * kWave, stream_));   // every entry is a tile offset at all times (k_pair_list reads ahead)
+    HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(int32_t) * 16, stream_));
+    listsOn_ = true;
+    listsValid_ = false;
+    if (std::getenv("AZTOT_VERBOSE"))
+        std::fprintf(stderr, "aztot: pair lists for %zu cells: %d candidates, %d iterations per cell (%.1f MB), LDS %zu B (list kernel) / %zu B (builder)\n", nc, candCap, iterCap,
+                     (double)(nc * ((size_t)candCap * 4 + (size_t)iterCap * 128)) / 1e6, pair_list_lds_bytes(P_, pair_lists()), build_lists_lds_bytes(pair_lists()));
+}
+
+void Engine::free_lists()
+{
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (dCandList_) (void)hipFree(dCandList_);
+    if (dListMeta_) (void)hipFree(dListMeta_);
+    if (dPairList_) (void)hipFree(dPairList_);
+    if (dNoList_) (void)hipFree(dNoList_);
+    if (dRel_) (void)hipFree(dRel_);
+    dRel_ = nullptr;
+    dCandList_ = nullptr; dListMeta_ = nullptr; dPairList_ = nullptr; dNoList_ = nullptr;
+    listsOn_ = false; listsValid_ = false;
+}
+
+PairLists Engine::pair_lists() const
+{
+    PairLists pl;
+    if (listsOn_)
+    {
+        pl.cand = dCandList_; pl.meta = dListMeta_; pl.pairs = dPairList_; pl.noList = dNoList_;
+        pl.candCap = candCap_; pl.iterCap = iterCap_; pl.candLds = candLds_; pl.iterLds = iterLds_; pl.recBytes = pair_list_rec_bytes(P_); pl.entryScale = pair_list_entry_scale(P_);
+        pl.rel = dRel_;
+    }
+    return pl;
 }
 
 // Static per-atom tables of the bonded terms, keyed by atom id and replicated on every rank (like the reference's
@@ -745,10 +844,9 @@ void Engine::launch_pair()
         StepParams Q = P_;
         Q.fuseKick = fuseNow_ ? 1 : 0;
         // pair energies are looked at through the statistics of a call's last step only (finish_steps): the list kernel of every other step books none
-        // (debug bit 134217728: every step does).  Inside a graph the last step of the cycle is the one that may be the call's last
-        const bool wantEnergies = stepsLeftInRun_ == 0 || (opt_.reserved[0] & 134217728);
-        PairLists pl;
-        if (listsOn_) { pl.cand = dCandList_; pl.meta = dListMeta_; pl.pairs = dPairList_; pl.laneCnt = dLaneCnt_; pl.noList = dNoList_; }
+        // (options.energies_every_step: every step does).  Inside a graph the last step of the cycle is the one that may be the call's last
+        const bool wantEnergies = stepsLeftInRun_ == 0 || (debug_ & DBG_ENERGIES_EVERY_STEP);
+        const PairLists pl = pair_lists();
         if (overlapHalo_)
         {   // interior x-layers [2 hw, ncx - 2 hw) first; then, once the neighbours' coordinates have landed, the two runs of boundary layers
             const int plane = P_.nc[1] * P_.nc[2], hw = P_.hw[0];
@@ -788,7 +886,7 @@ void Engine::launch_pair()
                 // plain step until the next rebuild, it walks them; the clean-up launch stages the cells that keep no list
                 if (candMode_ == 1)
                 {   // (k_rank_gather has cleared the count of cells without a list)
-                    timed("build_lists", [&] { launch_build_lists(Q, S_, dPots_, cur(), dCounts_, dCellStart_, stream_, PairRange(), pl); });
+                    timed("build_lists", [&] { launch_build_lists(Q, dCellStart_, stream_, PairRange(), pl); });
                     listsValid_ = true;
                     unlistedState_ = 0;
                     if (nranks_ > 1 && !capturing_)
@@ -865,7 +963,7 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
     if (stepMode == 2)
     {   // plain step of the lazy re-sort: integrate only; slots, cells and buffers stay as they are
         if (preIntegrated_) preIntegrated_ = false;                 // the previous step's pair kernel has opened this step already (NextStep)
-        else if (nranks_ == 1 && P_.tstat != AZTOT_TSTAT_NOSE && !(opt_.reserved[0] & 16777216))
+        else if (nranks_ == 1 && P_.tstat != AZTOT_TSTAT_NOSE && !(debug_ & 16777216))
             // one GPU (the owned range starts at 0: 16-byte loads are aligned), nothing scales the velocities at the start of the step: two atoms per thread
             timed("integrate1", [&] {
                 hipLaunchKernelGGL(k_integrate_plain2, dim3(div_up(div_up(capacity_, 2), kBlock)), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dPartials_,
@@ -888,7 +986,7 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
             const int interiorLayers = P_.ncxLocal - 4 * P_.hw[0];
             // OPT-IN (debug bit 16384): measured on one rank of 7 (loopback) the two cross-stream event waits and the two extra launches cost 30 us
             // where the exchange they hide takes 7 (0.0685 -> 0.0981 ms/step), so the default is the serial order
-            overlapHalo_ = !profile_ && xch_->device_side() && pair_variant() == 2 && interiorLayers >= 1 && (opt_.reserved[0] & 16384);
+            overlapHalo_ = !profile_ && xch_->device_side() && pair_variant() == 2 && interiorLayers >= 1 && (debug_ & 16384);
             if (overlapHalo_)
             {
                 HIP_CHECK(hipEventRecord(evIntegrated_, stream_));
@@ -939,7 +1037,7 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
     timed("rank_gather", [&] {
         hipLaunchKernelGGL(k_rank_gather, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellStart_, dTmpId_, dTmpSrc_, dTmpCell_, cur(), oth(),
                            dCellOfSorted_, (P_.tstat == AZTOT_TSTAT_RADI || P_.use_radii || thermoTouched_) ? 2 : 0, P_, dCounts_, bonded_.idxOfId, bins_, ref_,
-                           dHaloInfo_, (listsOn_ && stepMode == 1 && lazyOn_ && lazyK_ > 1) ? dNoList_ + 2 : nullptr);
+                           dHaloInfo_, (listsOn_ && stepMode == 1 && lazyOn_ && lazyK_ > 1) ? dNoList_ + 2 : nullptr, listsOn_ ? dRel_ : nullptr);
     });
     cur_ ^= 1;
     sinceSort_ = 0;
@@ -1017,9 +1115,9 @@ void Engine::launch_step_kernels()
     ekinFromPair_ = fused;
     // radiative thermostat without equilibration scaling: nothing global happens between the second half-kick and the thermostat - one launch (debug bit
     // 4194304: two, as everywhere else)
-    const bool kickAndPost = !fused && !lazyKick_ && !equil && P_.tstat == AZTOT_TSTAT_RADI && !(opt_.reserved[0] & 4194304);
+    const bool kickAndPost = !fused && !lazyKick_ && !equil && P_.tstat == AZTOT_TSTAT_RADI && !(debug_ & 4194304);
     // ... and when a plain step follows, the same launch opens it (k_boundary_radi; debug bit 33554432: no)
-    if (kickAndPost && nextPlain && !(opt_.reserved[0] & 33554432))
+    if (kickAndPost && nextPlain && !(debug_ & 33554432))
     {
         StepParams Q = P_;
         Q.cycleStep = sinceSort_ + 1;              // of the step being opened
@@ -1117,11 +1215,11 @@ int Engine::graph_cycle() const
 bool Engine::can_graph() const
 {
     // slab ranks: only with the loopback transport and only on request (debug bit 4096) - an experiment, see DESIGN.md section 6
-    const bool slabGraph = nranks_ > 1 && ownedXch_ && (opt_.reserved[0] & 4096) && !(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE);
+    const bool slabGraph = nranks_ > 1 && ownedXch_ && (debug_ & 4096) && !(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE);
     // Replaying captured cycles pays where a step is a handful of microsecond kernels.  On 1 M atoms the kernels are long enough for plain asynchronous
     // launches to keep the GPU busy, and each hipGraphLaunch costs a 40 us bubble in front of its first kernel (rocprofv3 kernel trace): 0.1594 ms/step
     // replayed, 0.1575 launched one by one; 40 000 atoms: 0.0184 replayed, 0.0187 one by one.  (Debug bit 8388608: replay whatever the size.)
-    const bool worthIt = capacity_ <= 2 * kFuseKickMaxAtoms || (opt_.reserved[0] & 8388608);
+    const bool worthIt = capacity_ <= 2 * kFuseKickMaxAtoms || (debug_ & 8388608);
     return opt_.use_graph && worthIt && (nranks_ == 1 || slabGraph) && !profile_;
 }
 
@@ -1209,11 +1307,10 @@ void Engine::prepare_next_call()
     if (!lazyOn_ || !lazyMeasured_) return;
     if (listsOn_ && lazyK_ > 1 && !listsValid_ && sinceSort_ == 0 && pair_variant() == 2)
     {
-        PairLists pl;
-        pl.cand = dCandList_; pl.meta = dListMeta_; pl.pairs = dPairList_; pl.laneCnt = dLaneCnt_; pl.noList = dNoList_;
+        const PairLists pl = pair_lists();
         P_.cycleStep = 0;
         HIP_CHECK(hipMemsetAsync(dNoList_ + 2, 0, sizeof(int32_t), stream_));
-        launch_build_lists(P_, S_, dPots_, cur(), dCounts_, dCellStart_, stream_, PairRange(), pl);
+        launch_build_lists(P_, dCellStart_, stream_, PairRange(), pl);
         check_launch("list building");
         sync();
         {
@@ -1247,15 +1344,63 @@ void Engine::adapt_sort_interval()
 {
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
+    bool rebuildNeeded = false;                    // this rank's lists were re-allocated: the next step must rebuild (on every rank: rebuild steps carry the full exchange)
+    if (listsOn_)
+    {   // cells that keep no list are staged by the small clean-up launch: fine for a few, slow for many (stencils wider than one tile, cells of more than
+        // 64 atoms) - then the plain steps go back to staging every cell
+        int32_t nl[16];
+        HIP_CHECK(hipMemcpy(nl, dNoList_, sizeof(nl), hipMemcpyDeviceToHost));
+        if ((debug_ & 2097152) && nl[1] > 0)
+        {   // measurement aid: mean list length / tile size / atoms per cell over the cells recorded since the last look
+            std::fprintf(stderr, "aztot: per cell: %.2f list iterations, %.1f candidates, %.2f atoms\n", (double)nl[8] / nl[1], (double)nl[9] / nl[1], (double)nl[10] / nl[1]);
+            HIP_CHECK(hipMemset(dNoList_ + 8, 0, sizeof(int32_t) * 3));
+        }
+        if (nl[1] > 0)
+        {
+            HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(int32_t) * 2, stream_));          // ([2] stays: it describes the lists in force; [3], [4] are all-time maxima)
+            HIP_CHECK(hipMemsetAsync(dNoList_ + 5, 0, sizeof(int32_t) * 2, stream_));
+            if (std::getenv("AZTOT_VERBOSE"))
+                std::fprintf(stderr, "aztot: lists recorded since the last look: %d cells, %d of them without a list (%d: tile full, %d: list full); largest tile %d of %d (LDS %d), longest list %d of %d (LDS %d)\n",
+                             nl[1], nl[0], nl[5], nl[6], nl[3], candCap_, candLds_, nl[4], iterCap_, iterLds_);
+            // LDS per wave is what bounds the occupancy of k_pair_list: the tiles are sized from the largest cell ever recorded (+ 6 %), not from the
+            // capacity of the arrays.  A cell that does not fit next time keeps no list for one interval (exact: the clean-up launch serves it) and is
+            // counted; then the tiles grow again.
+            int candLds = std::max(kListMinCand, std::min(candCap_, (nl[3] + nl[3] / 16 + 8 + 63) & ~63));
+            int iterLds = std::max(2 * kListMinIter, std::min(iterCap_, (nl[4] + nl[4] / 8 + 2 + 7) & ~7));
+            if (nl[5] > 0) candLds = std::min(candCap_, std::max(candLds, candLds_ + 64));
+            if (nl[6] > 0) iterLds = std::min(iterCap_, std::max(iterLds, iterLds_ + 8));
+            if (debug_ & 65536) { candLds = candLds_; iterLds = iterLds_; }
+            const bool capFull = (nl[5] > 0 && candLds_ == candCap_) || (nl[6] > 0 && iterLds_ == iterCap_);
+            if (capFull && !(debug_ & 65536) && (double)(nl[5] + nl[6]) > 0.0005 * (double)nl[1])
+            {   // the arrays themselves are too small: larger ones if the limits allow (twice), and the next step rebuilds; else - cells of more than 64 atoms
+                // never fit - the plain steps go back to staging once that is more than 2 % of the cells
+                const int cand = nl[5] > 0 ? std::min(kListCandMax, (candCap_ * 3 / 2 + 63) & ~63) : candCap_;
+                const int iters = nl[6] > 0 ? std::min(kListIterMax, (iterCap_ * 2 + 7) & ~7) : iterCap_;
+                destroy_graphs(); graphCycle_ = 0;
+                if (listGrowths_ < 3 && (cand > candCap_ || iters > iterCap_)) { listGrowths_++; allocate_lists(cand, iters); rebuildNeeded = true; }
+            }
+            else if (candLds != candLds_ || iterLds != iterLds_)
+            {
+                candLds_ = candLds; iterLds_ = iterLds;
+                destroy_graphs(); graphCycle_ = 0;        // (launch parameters are baked into the graphs)
+            }
+            if (listsOn_ && (double)nl[0] > 0.02 * (double)nl[1] && !(debug_ & 65536) && nl[5] + nl[6] < nl[0] / 2)
+            {   // mostly cells of more than 64 atoms: no list will ever hold them
+                listsOn_ = false; listsValid_ = false; destroy_graphs(); graphCycle_ = 0;
+            }
+        }
+    }
     if (nranks_ > 1)
-    {   // every rank must arrive at the same interval (sort steps carry the full exchange) and at the same verdict: one slot per rank + the flag
-        double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    {   // every rank must arrive at the same interval (sort steps carry the full exchange) and at the same verdict: one slot per rank + the flags
+        double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        v[10] = rebuildNeeded ? 1.0 : 0.0;
         double mine;
         std::memcpy(&mine, &c.maxStep2, sizeof(mine));
         if (nranks_ <= 8) v[rank_] = mine; else v[0] = 0.0;
         v[8] = c.lazyViolatedEver ? 1.0 : 0.0;
         v[9] = nranks_ > 8 ? mine : 0.0;              // more than 8 ranks: sum of squares bounds the maximum from above (conservative)
-        xch_->allreduce_sum(v, 10, stream_);
+        xch_->allreduce_sum(v, 11, stream_);
+        rebuildNeeded = v[10] > 0.0;
         double mx = v[9];
         for (int k = 0; k < 8; k++) mx = std::max(mx, v[k]);
         std::memcpy(&c.maxStep2, &mx, sizeof(mx));
@@ -1266,32 +1411,14 @@ void Engine::adapt_sort_interval()
             HIP_CHECK(hipMemcpy(&dCounts_->lazyViolatedEver, &z, sizeof(z), hipMemcpyHostToDevice));
             lazyK_ = 1; lazyMeasured_ = false; lazyWindow_ = 8; lazyViolations_++;
             throw std::runtime_error("lazy re-sort on slab ranks: an atom left its cell's slack between two sorts (the speeds grew more than fourfold within one "
-                                     "interval); the forces of this call are not exact - restart from the last state with options.reserved[2] = 1");
+                                     "interval); the forces of this call are not exact - restart from the last state with options.sort_every = 1");
         }
     }
     HIP_CHECK(hipMemsetAsync(&dCounts_->maxStep2, 0, sizeof(unsigned long long), stream_));      // (in stream order: no second round trip for the look)
+    if (rebuildNeeded) { sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false; }
     lazyMeasured_ = true;
-    if (listsOn_)
-    {   // cells that keep no list are staged by the small clean-up launch: fine for a few, slow for many (stencils wider than one tile, cells of more than
-        // 64 atoms) - then the plain steps go back to staging every cell
-        int32_t nl[2] = {0, 0};
-        HIP_CHECK(hipMemcpy(nl, dNoList_, sizeof(nl), hipMemcpyDeviceToHost));
-        if (opt_.reserved[0] & 2097152)
-        {   // measurement aid: mean list length / tile size / atoms per cell over the cells recorded since the last look
-            int32_t q[8];
-            HIP_CHECK(hipMemcpy(q, dNoList_, sizeof(q), hipMemcpyDeviceToHost));
-            if (q[1] > 0) std::fprintf(stderr, "aztot: per cell: %.2f list iterations, %.1f candidates, %.2f atoms\n", (double)q[3] / q[1], (double)q[4] / q[1], (double)q[5] / q[1]);
-            HIP_CHECK(hipMemset(dNoList_ + 3, 0, sizeof(int32_t) * 3));
-        }
-        if (nl[1] > 0)
-        {
-            HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(nl), stream_));          // ([2] stays: it describes the lists in force)
-            if (std::getenv("AZTOT_VERBOSE")) std::fprintf(stderr, "aztot: lists recorded since the last look: %d cells, %d of them without a list\n", nl[1], nl[0]);
-            if ((double)nl[0] > 0.02 * (double)nl[1] && !(opt_.reserved[0] & 65536)) { listsOn_ = false; destroy_graphs(); graphCycle_ = 0; }
-        }
-    }
     int K = lazyK_;
-    if (opt_.reserved[0] & 8192)
+    if (debug_ & 8192)
     {   // debug: fixed interval whatever the speeds (exercises the wider-stencil fallback); violations are only counted
         if (c.lazyViolatedEver)
         {
@@ -1320,7 +1447,7 @@ void Engine::adapt_sort_interval()
             const double raw = len > 0 ? lazySlack_ / ((nranks_ > 1 ? 4.0 : lazyMargin_) * len) : 1e9;
             if (std::getenv("AZTOT_VERBOSE"))
                 std::fprintf(stderr, "aztot: longest step %.3e A, slack %.3e A, margin %.2f%s: interval up to %.1f steps\n", len, lazySlack_, lazyMargin_, violated ? ", violated" : "", raw);
-            static const int allowed[] = {32, 28, 24, 20, 16, 14, 12, 10, 8, 6, 5, 4, 3, 2, 1};
+            static const int allowed[] = {64, 56, 48, 40, 36, 32, 28, 24, 20, 16, 14, 12, 10, 8, 6, 5, 4, 3, 2, 1};
             fromSpeed = 1;
             for (int a : allowed) if (a <= lazyCap_ && (double)a <= raw) { fromSpeed = a; break; }
         }
@@ -1475,6 +1602,11 @@ void Engine::set_state(const aztot_state& in)
 {
     sync();
     sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false;       // the next call rebuilds the cells
+    if (in.vx || in.vy || in.vz || in.fx || in.fy || in.fz)
+    {   // new velocities / forces: the interval measured on the old ones says nothing about them - every step rebuilds until the first look
+        if (lazyK_ != 1 && !(debug_ & 8192)) { lazyK_ = 1; destroy_graphs(); graphCycle_ = 0; }
+        lazyMeasured_ = false; lazyWindow_ = 8;
+    }
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
     const int n = c.ownedEnd - c.ownedBegin;

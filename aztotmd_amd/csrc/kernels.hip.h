@@ -730,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
                                                         const int32_t* __restrict__ tmpCell, AtomArrays src, AtomArrays dst,
                                                         int32_t* __restrict__ cellOfSorted, int carryForces /* bit 0: forces, bit 1: U + radius */, StepParams P, Counts* cntOut,
                                                         int32_t* __restrict__ idxOfId, CellBins B, RefPos R0, int32_t* __restrict__ haloInfo,
-                                                        int32_t* __restrict__ zeroMe)
+                                                        int32_t* __restrict__ zeroMe, float4* __restrict__ rel)
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p == 0)
@@ -761,6 +761,15 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
     const double x = src.x[i], y = src.y[i], z = src.z[i];
     dst.x[d] = x; dst.y[d] = y; dst.z[d] = z;
     if (R0.x) { R0.x[d] = x; R0.y[d] = y; R0.z[d] = z; }         // lazy re-sort: displacements are measured from here
+    if (rel)
+    {   // what the list builder stages (k_build_lists): the position relative to the centre of the cell the atom was binned into (count_cell:
+        // floor(x * cRevSize)), f32, and that cell's z index - a neighbour's position relative to ANOTHER cell's centre is then this plus whole cell edges
+        const int gz = cell_coord(z, P.icsz[2], P.nc[2]);
+        const double cx = cell_coord(x, P.icsz[0], P.nc[0]) * P.csz[0] + 0.5 * P.csz[0];
+        const double cy = cell_coord(y, P.icsz[1], P.nc[1]) * P.csz[1] + 0.5 * P.csz[1];
+        const double cz = gz * P.csz[2] + 0.5 * P.csz[2];
+        rel[d] = make_float4((float)(x - cx), (float)(y - cy), (float)(z - cz), (float)gz);
+    }
     if (B.x)
     {   // the same atom in its cell's bins, relative to the centre of the cell it was binned into (count_cell: floor(x * cRevSize))
         if (rank < 16 * B.perCell)

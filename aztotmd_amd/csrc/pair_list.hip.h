@@ -1,27 +1,54 @@
-// Pair-force kernel of a lazy run (every step: plain steps and - after the lists have been made - the rebuild steps too): one wave64 per cell,
-// driven by the lists the last rebuild of the cells recorded.
+// Pair lists of the lazy re-sort: the kernel that builds them on the step that rebuilds the cells (k_build_lists) and the pair-force kernel that walks
+// them on every step of a lazy run (k_pair_list).  One wave64 per cell in both.
 //
 // Replaces the reference's cell_list5a + cell_list4b_noshared + pair_1 (cuPairs.cu:2266,1474,117).  The reference rebuilds everything every step
-// (main.cu:300-326); here the step that rebuilds the cells (BUILD instantiation of k_pair_tile, pair_tile.hip.h) leaves two lists per cell:
-//   * the candidates of the cell's tile (atom index + periodic image code), and
-//   * for every atom of the cell the candidates within rc + 2 slack, dealt round-robin to the lanes that serve the atom.
-// Until the next rebuild atoms keep their slots and nobody moves farther than the slack (checked every step by whoever integrates; a violation
-// makes this kernel stand down and the clean-up launch of k_pair_tile stage everything with a wider stencil), so a step is
-//   1. gather the candidates into LDS (coordinates relative to the cell centre, as in k_pair_tile: same numbers, same arithmetic);
-//   2. every lane walks ITS list: entry -> LDS byte offset -> exact r^2 <= rc^2 test -> potential (pair_body, shared with k_pair_tile);
+// (main.cu:300-326); here the cells are rebuilt every K-th step only (Engine::step) and the rebuild leaves two lists per cell:
+//   * the candidates: every atom of the cell's stencil within rc + skin of the cell's box (atom index + periodic image code, tile order), and
+//   * for every atom of the cell its partners among them - the candidates within rc + skin of the atom -, dealt round-robin to the lanes that
+//     serve the atom.  An entry is the byte offset of the candidate's record in the LDS tile of k_pair_list.
+// Until the next rebuild atoms keep their slots and nobody moves farther than skin / 2 (checked every step by whoever integrates; a violation makes
+// k_pair_list stand down and the clean-up launch of k_pair_tile stage everything with a wider stencil), so no pair inside rc can be missing and a step is
+//   1. gather the candidates into LDS (coordinates relative to the cell centre: same numbers, same arithmetic as k_pair_tile);
+//   2. every lane walks ITS list: entry -> LDS record -> exact r^2 <= rc^2 test -> potential (pair_body, shared with k_pair_tile);
 //   3. optionally (NextStep, small systems) the epilogue opens the next step: second half-kick, first half-kick, drift.
-// No run table, no pruning, no compaction, no distance filter, no bit masks; and because an atom's partners were dealt evenly, the lanes of a
-// wave finish together (the mask-popping loop of k_pair_tile runs max-over-lanes = 21 iterations for a mean of 14 on the 1 M-atom box; here 14).
-// Forces: written once per atom, no atomics, fixed summation order => bit-reproducible.  HBM traffic: the lists are streamed once per step
-// (coalesced: 4 B per candidate, 2 B per pair entry), which is what buys the 3x in vector instructions.
+// Lanes are (atom slot, slice) with slot = lane / NS and NS = min(8, 64 / atoms in the cell) slices per atom: 13-16 atoms run 4 slices each, 17-21
+// three, 22-32 two - whatever the cell holds, at least two thirds of the lanes work (the power-of-two layout of round 2 fell to half at 17 atoms, which
+// is what a liquid's cells of rc + skin hold).  Slices of one atom are neighbouring lanes: they are folded with lane shifts in a fixed order.
+// Forces: written once per atom, no atomics, fixed summation order => bit-reproducible.  All list sizes are per engine (PairLists::candCap / iterCap,
+// dynamic LDS), so dense systems (hundreds of partners per atom, a thousand candidates per cell) walk lists too.
 #pragma once
 #include "pair_tile.hip.h"
 
 namespace aztot {
 
+constexpr int kListPreload = 5;            // groups of 64 candidate entries every wave of k_pair_list asks for before it knows the cell's T (candCap >= 320)
+constexpr int kListMinCand = 64 * kListPreload;
+constexpr int kListMinIter = 16;           // two chunks of 8 iterations are asked for up front
+constexpr int kListMaxSlices = 8;
+
+__host__ __device__ inline int list_slices(int nAtoms) { const int n = kWave / (nAtoms > 0 ? nAtoms : 1); return n > kListMaxSlices ? kListMaxSlices : (n < 1 ? 1 : n); }
+
+// LDS of k_pair_list by kernel mode (LDS per wave bounds its occupancy, so every byte per candidate counts):
+//   one species, LJ (MODE 1)            records {x, y, z} of 24 B; a list entry is the record's byte offset
+//   table-driven modes (2, 3, 5)        [pair table 1 KiB][species bytes, kListTypeBytes][records of 24 B]; a list entry is the record NUMBER (the species byte
+//                                       sits at a fixed offset + number, the record at number x 24 + base: one v_mad more per visit, 8 B less per candidate)
+//   radii (MODE 4) / generic (MODE 0)   records {x, y, z, radius} of 32 B, entry = byte offset [+ species bytes behind the records]
+inline bool pair_list_tab_mode(const StepParams& P) { return P.pad1 == 2 && !P.single_lj; }
+inline size_t pair_list_lds_bytes(const StepParams& P, const PairLists& L)
+{
+    const bool tab = pair_list_tab_mode(P);
+    const bool generic = !P.single_lj && P.pad1 != 2 && P.pad1 != 4;
+    size_t b = (size_t)(L.candLds + 1) * L.recBytes;
+    if (tab) b += sizeof(double) * kLjSpecMax * kLjSpecMax * kPairTabStride + (((size_t)L.candLds + 1 + 15) & ~(size_t)15);
+    if (generic) b += (size_t)(L.candLds + 1 + 7) & ~(size_t)7;
+    return b;
+}
+inline int pair_list_rec_bytes(const StepParams& P) { return (P.single_lj || pair_list_tab_mode(P)) ? 24 : 32; }
+inline int pair_list_entry_scale(const StepParams& P) { return pair_list_tab_mode(P) ? 1 : pair_list_rec_bytes(P); }     // what the builder multiplies a record number by
+
 // ENG = false: the launch books no energies (steps whose energies nobody can see: all but the last step of an aztot_step call - the statistics are those of
 // the last step, finish_steps; the reference prints them every `stat` steps, cuStat.cu:308-330).  Forces are the same instructions either way: the energy
-// terms feed nothing else, the compiler drops them and their two wave reductions (C4: 603 -> 540 vector instructions per cell).
+// terms feed nothing else, the compiler drops them and their two wave reductions.
 template <int MODE, int VDW, bool ENG>
 __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
@@ -30,10 +57,15 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
 {
     constexpr bool kOneSpecies = (MODE == 1 || MODE == 4);           // no species table, no type ids
     constexpr bool kRadii = (MODE == 0 || MODE == 4);
-    __shared__ double txyz[3 * kTileLds];                            // candidate coordinates RELATIVE to the centre of the centre cell
-    __shared__ uint8_t ttyp[!kOneSpecies ? kTileLds : 1];            // species ids (< 16)
-    __shared__ double trad[kRadii ? kTileLds : 1];
-    __shared__ double pairTab[(MODE == 2 || MODE == 3 || MODE == 5) ? kLjSpecMax * kLjSpecMax * kPairTabStride : 1];
+    constexpr bool kTab = (MODE == 2 || MODE == 3 || MODE == 5);
+    constexpr int RECB = (MODE == 1 || kTab) ? 24 : 32;              // record {x, y, z [, radius]} RELATIVE to the centre of the cell
+    constexpr int ESCALE = kTab ? 24 : 1;                            // list entry -> byte offset of the record (table modes keep record numbers)
+    constexpr int kTabDoubles = kTab ? kLjSpecMax * kLjSpecMax * kPairTabStride : 0;
+    extern __shared__ double ldsList[];
+    double* const pairTab = ldsList;
+    uint8_t* const ttypT = (uint8_t*)(ldsList + kTabDoubles);        // table modes: species ids by record number, at a compile-time offset
+    char* const tb = (char*)(ldsList + kTabDoubles) + (kTab ? ((L.candLds + 1 + 15) & ~15) : 0);
+    uint8_t* const ttyp0 = (uint8_t*)(tb + (size_t)(L.candLds + 1) * RECB);      // MODE 0 only: species ids (by record number)
 
     const int lane = threadIdx.x;
     const int per = (nCellsRun + 7) >> 3;
@@ -44,21 +76,20 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     // after a slack violation (one GPU) the clean-up launch stages every cell with the wider stencil: stand down
     const bool violated = P.nranks == 1 && slack_violated(P, counts);
     // everything that depends on the cell number only is requested at once, before anything is known about the cell (the loads stay inside the
-    // arrays whatever they return): list header, the five groups of candidate entries, the lane's first two list chunks and entry count.  A wave's
-    // life is then two memory round trips (these, then the coordinates) and the loop
+    // arrays whatever they return): list header, five groups of candidate entries, the lane's first two list chunks.  A wave's life is then two
+    // memory round trips (these, then the coordinates) and the loop
     const int cell = firstCell + min(cr, nCellsRun - 1);
-    const uint32_t* const myList = L.cand + (size_t)cell * kTileCap + lane;
-    const uint4* const pl = (const uint4*)(L.pairs + (size_t)cell * kListStride16) + lane;
-    constexpr int kRounds = kTileCap / kWave;
-    uint32_t ent[kRounds];
+    const uint32_t* const myList = L.cand + (size_t)cell * L.candCap + lane;
+    const uint4* const pl = (const uint4*)(L.pairs + (size_t)cell * L.iterCap * kWave) + lane;
+    uint32_t ent[kListPreload];
 #pragma unroll
-    for (int u = 0; u < kRounds; u++) ent[u] = myList[u * kWave];
+    for (int u = 0; u < kListPreload; u++) ent[u] = myList[u * kWave];
     uint4 w = pl[0];
     uint4 w1 = pl[kWave];                                           // (the second chunk too: 16 iterations cover a liquid's cells, and a chunk asked for only
                                                                     //  8 iterations ahead arrives late)
     const int2 mx = ((const int2*)L.meta)[cell];                   // {list header, cell coordinates lx | cy << 10 | cz << 20}: one scalar load, no integer divisions
     int meta = mx.x;
-    if (violated || cr >= nCellsRun) meta = -1;
+    if (violated || cr >= nCellsRun || !list_usable(L, meta)) meta = -1;         // (a cell that does not walk its list is served by the clean-up launch)
     if (meta > 0)
     {
         const int T = meta & 0xFFF, nIter = meta >> 12;
@@ -67,7 +98,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         const int ib = cellStart[cell], ie = cellStart[cell + 1];
         const double cc0 = (lx + P.cx0) * P.csz[0] + 0.5 * P.csz[0], cc1 = cy * P.csz[1] + 0.5 * P.csz[1], cc2 = cz * P.csz[2] + 0.5 * P.csz[2];
         const DevPot lj = pots[0];
-        if (MODE == 2 || MODE == 3 || MODE == 5)
+        if (kTab)
         {
             const int np = P.nSpec * P.nSpec;
             if (lane < np)
@@ -82,13 +113,13 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
                 q[7] = (double)v.type;
             }
         }
-        // ---- the cell's own atoms: lanes are (atom slot, slice) as in k_pair_tile
-        const int nthis = ie - ib;                                     // <= 64 (cells with more keep no list)
-        const int lg = nthis <= 16 ? 4 : (nthis <= 32 ? 5 : 6);
-        const int islots = 1 << lg;
-        const int il = lane & (islots - 1), slice = lane >> lg;
-        const bool validI = il < nthis;
-        const int myi = ib + il;
+        // ---- the cell's own atoms: lane = slot * NS + slice
+        const int nthis = ie - ib;                                     // 1 .. 64 (cells with more keep no list)
+        const int NS = list_slices(nthis);
+        const int rcpNS = 65536 / NS + 1;
+        const int slot = (lane * rcpNS) >> 16, slice = lane - slot * NS;
+        const bool validI = slot < nthis;
+        const int myi = ib + slot;
         // (every lane loads - idle atom slots from the cell's first atom - so that the three loads travel together; a conditional load made the compiler
         //  wait for each of them in turn)
         const int myl = validI ? myi : ib;
@@ -101,8 +132,8 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         int ti = 0;
         if (!kOneSpecies) ti = A.type[myl];
         if ((MODE == 0 && P.use_radii) || MODE == 4) radi = A.rad[myl];
-        // ---- gather the candidates (groups of 64; the record padded the last group with a valid atom).  Four groups are gathered whatever T is (stale
-        // entries are atom indices too: the array starts out zeroed and only indices are ever written), the fifth when T > 256; all loads travel together
+        // ---- gather the candidates (groups of 64; the builder padded the last group with a valid atom).  Five groups are gathered whatever T is (stale
+        // entries are atom indices too: the array starts out zeroed and only indices are ever written); all their loads travel together
         {
             const int gx0 = lx + P.cx0;
             // does any neighbour cell lie across a periodic boundary (or the seam of a slab ring)?  wave-uniform
@@ -124,26 +155,43 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
                     yj += (double)((int)((e >> 28) & 3u) - 1) * P.L[1];
                     zj += (double)((int)((e >> 30) & 3u) - 1) * P.L[2];
                 }
-                const int pq = u * kWave + lane;
-                txyz[pq] = xj - cc0; txyz[kTileLds + pq] = yj - cc1; txyz[2 * kTileLds + pq] = zj - cc2;
-                if (!kOneSpecies) ttyp[pq] = (uint8_t)c.typ;
-                if (kRadii) trad[pq] = c.rad;
+                char* const r = tb + (size_t)(u * kWave + lane + 1) * RECB;       // candidate k -> record k + 1 (record 0 is the dummy)
+                *(double*)r = xj - cc0; *(double*)(r + 8) = yj - cc1; *(double*)(r + 16) = zj - cc2;
+                if (kTab) ttypT[u * kWave + lane + 1] = (uint8_t)c.typ;
+                if (kRadii) *(double*)(r + 24) = c.rad;
+                if (MODE == 0) ttyp0[u * kWave + lane + 1] = (uint8_t)c.typ;
             };
             const Cand c0 = fetch(ent[0]), c1 = fetch(ent[1]), c2 = fetch(ent[2]), c3 = fetch(ent[3]);
             if (T > 4 * kWave)
             {
                 const Cand c4 = fetch(ent[4]);
                 put(0, ent[0], c0); put(1, ent[1], c1); put(2, ent[2], c2); put(3, ent[3], c3); put(4, ent[4], c4);
+                // dense systems: the rest of the tile, four groups per round trip
+                for (int u0 = kListPreload; u0 * kWave < T; u0 += 4)
+                {
+                    uint32_t en[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) en[q] = ((u0 + q) * kWave < T) ? myList[(u0 + q) * kWave] : ent[0];
+                    const Cand d0 = fetch(en[0]), d1 = fetch(en[1]), d2 = fetch(en[2]), d3 = fetch(en[3]);
+                    put(u0, en[0], d0);
+                    if ((u0 + 1) * kWave < T) put(u0 + 1, en[1], d1);
+                    if ((u0 + 2) * kWave < T) put(u0 + 2, en[2], d2);
+                    if ((u0 + 3) * kWave < T) put(u0 + 3, en[3], d3);
+                }
             }
             else { put(0, ent[0], c0); put(1, ent[1], c1); put(2, ent[2], c2); put(3, ent[3], c3); }
         }
+        // idle atom slots sit far away on the other side of the dummy candidate, so that nothing they meet is inside a cut-off
         const double xi = validI ? xr - cc0 : 1e30, yi = validI ? yr - cc1 : 1e30, zi = validI ? zr - cc2 : 1e30;
-        // the dummy candidate the unused list entries point at (kListDummy): far outside any cut-off, with a species and a radius the potentials can digest
+        // the dummy candidate the unused list entries (0) point at: far outside any cut-off, with a species and a radius the potentials can digest
+        constexpr uint32_t dummyOff = 0u;
         if (lane == 0)
         {
-            txyz[kTileLds - 1] = 1e30; txyz[2 * kTileLds - 1] = 1e30; txyz[3 * kTileLds - 1] = 1e30;
-            if (!kOneSpecies) ttyp[kTileLds - 1] = 0;
-            if (kRadii) trad[kTileLds - 1] = 1.0;
+            char* const r = tb;
+            *(double*)r = -1e30; *(double*)(r + 8) = -1e30; *(double*)(r + 16) = -1e30;
+            if (kTab) ttypT[0] = 0;
+            if (kRadii) *(double*)(r + 24) = 1.0;
+            if (MODE == 0) ttyp0[0] = 0;
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -151,21 +199,22 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         PairAcc acc = {0, 0, 0, 0, 0, 0};
         int nDropHalf = 0;
         const double ljDropR2 = P.ljDropR2;
-        const PairHot hot = (MODE == 2 || MODE == 3 || MODE == 5) ? pair_hot_in_vgprs(P) : pair_hot(P);
-        const char* const tb = (const char*)txyz;
+        const PairHot hot = kTab ? pair_hot_in_vgprs(P) : pair_hot(P);
         const int nChunks = (nIter + 7) >> 3;
         // software-pipelined: the candidate of iteration t + 1 is read from LDS before the potential of iteration t is evaluated (entries behind a lane's
-        // last one point at the dummy - the record fills the list buffer with kListDummy - so the read ahead is always a valid one)
+        // last one point at the dummy - the builder fills the list buffer with it - so the read ahead is always a valid one)
         double xj, yj, zj, radj = 0.0;
         int tj = 0;
-        auto fetch = [&](uint32_t ko, double& x, double& y, double& z, int& ty, double& rd) {
+        auto fetch = [&](uint32_t en, double& x, double& y, double& z, int& ty, double& rd) {
+            const uint32_t ko = en * ESCALE;                           // (table modes: one v_mad_u32_u24 with the records' base)
             x = *(const double*)(tb + ko);
-            y = *(const double*)(tb + ko + kTileLds * 8);
-            z = *(const double*)(tb + ko + 2 * kTileLds * 8);
-            if (!kOneSpecies) ty = ttyp[ko >> 3];
-            if (kRadii) rd = *(const double*)((const char*)trad + ko);
+            y = *(const double*)(tb + ko + 8);
+            z = *(const double*)(tb + ko + 16);
+            if (kTab) ty = ttypT[en];
+            if (kRadii) rd = *(const double*)(tb + ko + 24);
+            if (MODE == 0) ty = ttyp0[ko >> 5];                    // (RECB = 32: record number)
         };
-        fetch(nIter > 0 ? (w.x & 0xFFFFu) : kListDummy, xj, yj, zj, tj, radj);
+        fetch(nIter > 0 ? (w.x & 0xFFFFu) : dummyOff, xj, yj, zj, tj, radj);
         for (int c = 0; c < nChunks; c++)
         {
             uint4 wn = w1;
@@ -176,7 +225,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
             {
                 const int t = c * 8 + u;
                 if (t >= nIter) break;                                  // wave-uniform
-                const uint32_t kn = ((u + 1) & 1) ? (ww[(u + 1) >> 1] >> 16) : (ww[(u + 1) >> 1] & 0xFFFFu);      // byte offset of the next candidate in the tile
+                const uint32_t kn = ((u + 1) & 1) ? (ww[(u + 1) >> 1] >> 16) : (ww[(u + 1) >> 1] & 0xFFFFu);      // byte offset of the next candidate's record
                 double xn, yn, zn, radn = 0.0;
                 int tn = 0;
                 fetch(kn, xn, yn, zn, tn, radn);
@@ -191,12 +240,21 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         }
         if (MODE != 0) acc.dropped += 0.5 * (double)nDropHalf;
 
-        // fold the j-slices (fixed order) and write the force: clear_force + pair sums
-        for (int o = kWave >> 1; o >= islots; o >>= 1)
+        // fold the slices of every atom (neighbouring lanes, fixed order: slice 0 + slice 1 + ...) and write the force: clear_force + pair sums
+        if (NS == 4)
+        {   // (the usual case: two lane exchanges inside a quad)
+            acc.fx += __shfl_xor(acc.fx, 1, kWave); acc.fy += __shfl_xor(acc.fy, 1, kWave); acc.fz += __shfl_xor(acc.fz, 1, kWave);
+            acc.fx += __shfl_xor(acc.fx, 2, kWave); acc.fy += __shfl_xor(acc.fy, 2, kWave); acc.fz += __shfl_xor(acc.fz, 2, kWave);
+        }
+        else
         {
-            acc.fx += __shfl_xor(acc.fx, o, kWave);
-            acc.fy += __shfl_xor(acc.fy, o, kWave);
-            acc.fz += __shfl_xor(acc.fz, o, kWave);
+            const double px = acc.fx, py = acc.fy, pz = acc.fz;
+            for (int s = 1; s < NS; s++)
+            {
+                acc.fx += __shfl_down(px, s, kWave);
+                acc.fy += __shfl_down(py, s, kWave);
+                acc.fz += __shfl_down(pz, s, kWave);
+            }
         }
         if (validI && slice == 0)
         {
@@ -247,15 +305,320 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     else if (N.pendingAfter >= 0 && blockIdx.x == 0 && lane == 0) N.st->pendingKick = N.pendingAfter;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// k_build_lists: the step that rebuilds the cells makes the lists (geometry only - independent of the potential set; no forces: k_pair_list
+// computes that step's forces like any other's, so a run has ONE force kernel and one summation order).  Everything here is f32: the lists only
+// have to be a SUPERSET of the pairs within rc + skin (k_pair_list applies the exact fp64 cut-off test every step), and the sort leaves every atom's
+// position relative to the centre of its own cell as one float4 (PairLists::rel) - so a neighbour's position relative to THIS cell's centre is that
+// plus a whole number of cell edges, whatever the periodic wrap: no image shifts, no fp64, one 16-byte load per candidate.  Per cell, one wave:
+//   1. the z-runs of the stencil are looked up by the lanes in parallel; the loads of up to eight runs travel together (a wave's life is two memory
+//      round trips and the arithmetic);
+//   2. candidates are pruned against the cell's box and packed into LDS with wave ballot + popcount prefix, together with their list entries
+//      (atom index + image code, which k_pair_list needs for its fp64 gather);
+//   3. per group of 16 atoms of the cell ONE v_mfma_f32_16x16x4_f32 per 16 candidates tests 256 pairs against the list radius
+//      (D = thr - |ri - rj|^2 with a threshold widened by the f32 error bound: conservative);
+//   4. every lane pops its hits into its atom's stretch of a compact per-cell array; then every lane of k_pair_list's layout
+//      (lane = atom * NS + slice) reads ITS entries out of that array (entry slice + t NS of its atom) and the list leaves as whole 1 KiB chunks.
+// A cell whose candidates exceed the tile, whose lists exceed iterCap or that holds more than 64 atoms keeps no list (header -1): the clean-up
+// launch of k_pair_tile stages it on every step, and the engine grows the capacities when that happens.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+struct BuildLds
+{
+    int capS;            // floats per coordinate array: candLds + 16 (the matrix filter reads whole blocks of 16)
+    int nWords;          // 32-bit hit-mask words per lane and atom group: ceil(capS / 128)
+    int hitCap;          // entries of the compact hit array: iterLds x 64
+    __host__ __device__ BuildLds(int candLds, int iterLds) : capS(candLds + 16), nWords((candLds + 16 + 127) / 128), hitCap(iterLds * kWave) {}
+    __host__ __device__ size_t union_bytes() const { const size_t a = sizeof(uint32_t) * (size_t)capS, b = sizeof(uint16_t) * (size_t)hitCap; return ((a > b ? a : b) + 15) & ~(size_t)15; }
+    __host__ __device__ size_t bytes() const { return sizeof(float) * 4 * (size_t)capS + union_bytes() + sizeof(uint32_t) * (size_t)nWords * kWave; }
+};
+
+__global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun, PairLists L)
+{
+    extern __shared__ float ldsBuild[];
+    const BuildLds G(L.candLds, L.iterLds);
+    float* const tx = ldsBuild;
+    float* const ty = tx + G.capS;
+    float* const tz = ty + G.capS;
+    float* const tw = tz + G.capS;                                  // -(x^2 + y^2 + z^2): the C operand of the filter
+    uint32_t* const tent = (uint32_t*)(tw + G.capS);                // list entries of the candidates (atom index | image code << 26), tile order ...
+    uint16_t* const hits = (uint16_t*)tent;                         // ... and, once those have left, the compact hit array (entries of k_pair_list's lists, atom by atom)
+    uint32_t* const maskBuf = (uint32_t*)((char*)tent + G.union_bytes());      // [nWords][64] hit masks of the atom group in flight
+    __shared__ int32_t entJ[kWave], entN[kWave], entC[kWave];       // staging table: first atom, count (<= 64), codes ; later: tile slot / offset / hit count per atom
+
+    const int lane = threadIdx.x;
+    const int per = (nCellsRun + 7) >> 3;
+    const int cr = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // the mapping of k_pair_list: a cell is built and walked on the same XCD
+    if (blockIdx.x == 0 && lane == 0) atomicAdd(&L.noList[1], nCellsRun);      // cells recorded (one atomic per launch)
+    if (cr >= nCellsRun) return;
+    const int cell = firstCell + cr;
+    const int ncy = P.nc[1], ncz = P.nc[2];
+    const int cxyz = L.meta[2 * cell + 1];
+    const int lx = cxyz & 1023, cy = (cxyz >> 10) & 1023, cz = (cxyz >> 20) & 1023;
+    const int ib = cellStart[cell], ie = cellStart[cell + 1];
+    const int nthis = ie - ib;
+    if (nthis == 0) { if (lane == 0) L.meta[2 * cell] = 0; return; }            // an empty cell: a list with nothing in it
+    auto no_list = [&](int why) { if (lane == 0) { L.meta[2 * cell] = -1; atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); if (why) atomicAdd(&L.noList[why], 1); } };
+    if (nthis > kWave) { no_list(0); return; }
+    const int RECB = L.entryScale;                                  // record number -> list entry (k_pair_list's mode decides: byte offset or number)
+    const int candLds = L.candLds;
+    const float hf0 = (float)(0.5 * P.csz[0]), hf1 = (float)(0.5 * P.csz[1]), hf2 = (float)(0.5 * P.csz[2]);
+    const float cs0 = (float)P.csz[0], cs1 = (float)P.csz[1], cs2 = (float)P.csz[2];
+    // f32 pruning radius: the list radius + what rounding can do to a coordinate (an atom's own-cell offset is rounded to f32, |x| < a few cell edges:
+    // 2^-22 relative on the square is far more than that)
+    const float pruneF = (float)(P.pruneR2 * (1.0 + 1e-5));
+
+    // ---- staging: all z-runs are looked up by the lanes in parallel, packed into a table, loaded eight at a time
+    int T = 0;
+    bool overflow = false;
+    const int nSegTot = P.nOff[0] * P.nOff[1] * 3;
+    const int rcpOff1 = 65536 / P.nOff[1] + 1;
+    for (int sg0 = 0; sg0 < nSegTot && !overflow; sg0 += kWave)
+    {
+        int rjb = 0, rn = 0, rcode = 0;
+        {
+            const int sg = sg0 + lane;
+            const int col = (sg * 21846) >> 16, seg = sg - 3 * col;
+            const int ox = (col * rcpOff1) >> 16, oy = col - ox * P.nOff[1];
+            int nx = lx + ox - P.hw[0], cxs = 1;                      // image codes (for k_pair_list's fp64 gather): 0 -> -L, 1 -> 0, 2 -> +L
+            if (P.nranks > 1)
+            {   // slab window: ghost layers are resident; their coordinates are global, so k_pair_list shifts across the seam
+                const int gx = nx + P.cx0;
+                if (gx < 0) cxs = 0; else if (gx >= P.nc[0]) cxs = 2;
+            }
+            else if (nx < 0) { nx += P.nc[0]; cxs = 0; }
+            else if (nx >= P.nc[0]) { nx -= P.nc[0]; cxs = 2; }
+            int ny = cy + oy - P.hw[1], cys = 1;
+            if (ny < 0) { ny += ncy; cys = 0; } else if (ny >= ncy) { ny -= ncy; cys = 2; }
+            const int zlo = cz - P.hw[2], zhi = cz + P.hw[2];
+            int zs, ze, czs = 1;
+            bool have = sg < nSegTot;
+            if (seg == 0) { zs = max(zlo, 0); ze = min(zhi, ncz - 1); }
+            else if (seg == 1) { have = have && zlo < 0; zs = zlo + ncz; ze = ncz - 1; czs = 0; }
+            else { have = have && zhi >= ncz; zs = 0; ze = zhi - ncz; czs = 2; }
+            if (have)
+            {
+                const int colBase = (nx * ncy + ny) * ncz;
+                rjb = cellStart[colBase + zs];
+                rn = cellStart[colBase + ze + 1] - rjb;
+                // image code (6 bits) | x offset of the column in cells + 32 (6 bits) | y offset + 32 (6 bits)
+                rcode = cxs | (cys << 2) | (czs << 4) | ((ox - P.hw[0] + 32) << 6) | ((oy - P.hw[1] + 32) << 12);
+            }
+        }
+        while (__any(rn > 0) && !overflow)
+        {
+            const unsigned long long emask = __ballot(rn > 0);
+            const int nEnt = __popcll(emask);
+            if (rn > 0)
+            {
+                const int pe = lanes_below(emask);
+                entJ[pe] = rjb; entN[pe] = min(rn, kWave); entC[pe] = rcode;
+                rjb += kWave; rn -= kWave;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int e = 0; e < nEnt && !overflow; e += 8)
+            {
+                const int le = min(e + (lane & 7), nEnt - 1);
+                const int vj = entJ[le], vn = entN[le], vc = entC[le];
+                float4 g[8];
+                int gjn[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                {
+                    const int j = __builtin_amdgcn_readlane(vj, u) + lane;
+                    gjn[u] = (e + u < nEnt) ? __builtin_amdgcn_readlane(vn, u) : 0;
+                    g[u] = L.rel[j];                                   // (unconditional: the array is padded by a wave's width, lanes beyond the run are dropped below)
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                {
+                    if (gjn[u] > 0 && !overflow)
+                    {
+                        const int code = __builtin_amdgcn_readlane(vc, u);
+                        const float offx = (float)(((code >> 6) & 63) - 32) * cs0, offy = (float)(((code >> 12) & 63) - 32) * cs1;
+                        const float dzc = (float)((((code >> 4) & 3) - 1) * ncz - cz);          // cells along z between the candidate's cell (its own index rides in .w) and this one
+                        const float xf = g[u].x + offx, yf = g[u].y + offy, zf = fmaf(g[u].w + dzc, cs2, g[u].z);
+                        // distance from the cell's box: atoms farther than the list radius cannot be anybody's partner
+                        const float bx = fmaxf(fabsf(xf) - hf0, 0.0f), by = fmaxf(fabsf(yf) - hf1, 0.0f), bz = fmaxf(fabsf(zf) - hf2, 0.0f);
+                        const bool keep = (lane < gjn[u]) && (bx * bx + by * by + bz * bz) <= pruneF;
+                        const unsigned long long mask = __ballot(keep);
+                        const int nk = __popcll(mask);
+                        if (T + nk > candLds) { overflow = true; }
+                        else
+                        {
+                            if (keep)
+                            {
+                                const int pp = T + lanes_below(mask);
+                                tx[pp] = xf; ty[pp] = yf; tz[pp] = zf;
+                                tw[pp] = -(xf * xf + yf * yf + zf * zf);
+                                tent[pp] = (uint32_t)(__builtin_amdgcn_readlane(vj, u) + lane) | ((uint32_t)(code & 63) << 26);
+                            }
+                            T += nk;
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (overflow) { no_list(5); return; }
+    if ((P.pad0 & 3) == 1) return;                                 // (phase timing: staging only)
+
+    // ---- candidates: written out in whole groups of 64 (k_pair_list gathers whole groups: the last one is filled with a valid atom, the cell's first)
+    {
+        uint32_t* const myList = L.cand + (size_t)cell * L.candCap;
+        const int Tpad = (T + kWave - 1) & ~(kWave - 1);
+        for (int q = lane; q < Tpad; q += kWave) myList[q] = (q < T) ? tent[q] : ((uint32_t)ib | (0x15u << 26));
+    }
+    // far-away, finite dummies behind the last candidate: the filter reads whole blocks of 16
+    if (lane < 16) { tx[T + lane] = -1e30f; ty[T + lane] = 0.0f; tz[T + lane] = 0.0f; tw[T + lane] = -3e38f; }
+    // where the cell's own atoms sit in the tile (they are candidates too, unshifted): found by their list entries
+    for (int q = lane; q < T; q += kWave)
+    {
+        const uint32_t en = tent[q];
+        const int rel = (int)(en & 0x3FFFFFFu) - ib;
+        if ((en >> 26) == 0x15u && rel >= 0 && rel < nthis) entJ[rel] = q;
+    }
+    __builtin_amdgcn_wave_barrier();                                // (from here on the entries' place holds the hit array)
+
+    // ---- filter + compaction, one group of 16 atoms at a time.  Matrix operand maps (gfx950, v_mfma_f32_16x16x4_f32): A[row l & 15][k l >> 4],
+    // B[k l >> 4][col l & 15], C/D[row 4 (l >> 4) + reg][col l & 15].  Rows are fed in the order perm(c) = (c >> 2) + 4 (c & 3), which makes register r
+    // of lane (atom l & 15, quarter kq = l >> 4) the candidate 16 b + kq + 4 r of block b; the -|rj|^2 of those four arrive as the C operand.
+    const double h0 = 0.5 * P.csz[0], h1 = 0.5 * P.csz[1], h2 = 0.5 * P.csz[2];
+    const double rList = sqrt(P.pruneR2);
+    const double ext2 = (h0 + rList) * (h0 + rList) + (h1 + rList) * (h1 + rList) + (h2 + rList) * (h2 + rList);
+    const float thrList = (float)(P.pruneR2 + 1.9073486328125e-06 * (4.0 * ext2 + P.pruneR2));       // list radius^2 + 2^-19 x a bound of the f32 error
+    const int NS = list_slices(nthis);
+    const int rcpNS = 65536 / NS + 1;
+    const int nBlk = (T + 15) >> 4;
+    const int nW = (nBlk + 7) >> 3;
+    const int c16 = lane & 15, kq = lane >> 4;
+    const int permc = (c16 >> 2) + ((c16 & 3) << 2);
+    const float* const pa = (kq == 0 ? tx : kq == 1 ? ty : kq == 2 ? tz : tx) + permc;       // (lanes kq = 3 feed the constant 1: what they read is ignored)
+    const float* const pc = tw + kq;
+    int nIter = 0, hitBase = 0, tooLong = 0;
+    for (int g0 = 0; g0 < nthis; g0 += 16)
+    {
+        const int a = g0 + c16;
+        const bool validA = a < nthis;
+        // idle atom slots sit at 1e18: their column of the filter is hugely negative ("outside") whatever the candidate
+        float4 me = make_float4(1e18f, 1e18f, 1e18f, 0.f);
+        if (validA) me = L.rel[ib + a];
+        const float fB = (kq == 0) ? 2.0f * me.x : (kq == 1) ? 2.0f * me.y : (kq == 2) ? 2.0f * me.z : thrList - (me.x * me.x + me.y * me.y + me.z * me.z);
+        const int kSelf = validA ? entJ[a] : -1;
+        int h = 0;
+        for (int wd = 0; wd < nW; wd++)
+        {
+            uint32_t miss = 0xFFFFFFFFu;                              // one bit per candidate of the lane, 1 = outside; newest candidate in bit 0
+            const int nb = min(8, nBlk - 8 * wd);
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+            {
+                if (q < nb)
+                {
+                    const int o = (8 * wd + q) * 16;
+                    const float av = pa[o];
+                    const float aop = (kq == 3) ? 1.0f : av;
+                    const float4_t cw = {pc[o], pc[o + 4], pc[o + 8], pc[o + 12]};
+                    const float4_t d = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, fB, cw, 0, 0, 0);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[0]), 31);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[1]), 31);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[2]), 31);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[3]), 31);
+                }
+            }
+            // left-aligned: candidate number p of this word (p = 4 (block & 7) + r) sits at bit 31 - p
+            uint32_t m = ~miss << (32 - 4 * nb);
+            // the atom itself is a candidate of its own tile (always a hit): not a partner
+            if (kSelf >= 0 && (kSelf & 3) == kq && (kSelf >> 7) == wd) m &= ~(0x80000000u >> ((kSelf & 127) >> 2));
+            maskBuf[wd * kWave + lane] = m;
+            h += __popc(m);
+        }
+        // where this lane's hits go: behind those of the lower quarters of its atom, which come behind the atoms before it
+        int below = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int hq = __shfl(h, c16 | (q << 4), kWave);
+            below += (q < kq) ? hq : 0;
+            total += hq;
+        }
+        if (!validA) total = 0;
+        int incl = total;                                            // inclusive scan over the 16 atoms of the group (every quarter computes the same)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { const int up = __shfl_up(incl, o, 16); if (c16 >= o) incl += up; }
+        const int myOff = hitBase + incl - total;
+        hitBase += __shfl(incl, 15, 16);
+        if (validA && kq == 0) { entN[a] = myOff; entC[a] = total; }
+        nIter = max(nIter, ((total + NS - 1) * rcpNS) >> 16);
+        if (hitBase > G.hitCap) { tooLong = 1; break; }              // (wave-uniform)
+        if ((P.pad0 & 3) == 2) continue;                           // (phase timing: no compaction)
+        // candidate k = 128 wd + kq + 4 p sits in record k + 1 of k_pair_list's tile
+        uint16_t* dst = hits + myOff + below;
+        for (int wd = 0; wd < nW; wd++)
+        {
+            uint32_t cur = maskBuf[wd * kWave + lane];
+            const int base = (128 * wd + kq + 1) * RECB;
+            while (cur != 0u)
+            {
+                const int p = __clz(cur);
+                cur &= ~(0x80000000u >> p);
+                *dst++ = (uint16_t)(base + p * 4 * RECB);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    nIter = wave_max_int(nIter);
+    // (debug bit 65536, tests: lists hold 14 iterations only - part of a liquid's cells then keep no list and go through the clean-up launch)
+    const bool usable = !tooLong && nIter <= ((P.pad0 & 65536) ? 14 : L.iterCap);
+    if (usable)
+    {   // every lane of k_pair_list's layout collects ITS entries: lane = atom * NS + slice walks entries slice, slice + NS, ... of its atom; 0 = no candidate
+        const int slot = (lane * rcpNS) >> 16, slice = lane - slot * NS;
+        int off = 0, cnt = 0;
+        if (slot < nthis) { off = entN[slot]; cnt = entC[slot]; }
+        const uint16_t* const src = hits + off;
+        uint4* const out = (uint4*)(L.pairs + (size_t)cell * L.iterCap * kWave) + lane;
+        for (int c = 0; c * 8 < nIter; c++)
+        {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+                const int e = (c * 8 + u) * NS + slice;
+                v[u] = (e < cnt) ? (uint32_t)src[e] : 0u;
+            }
+            out[c * kWave] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+        }
+    }
+    if (lane == 0)
+    {
+        L.meta[2 * cell] = usable ? (T | (nIter << 12)) : -1;
+        if (T > L.noList[3]) atomicMax(&L.noList[3], T);           // (a read first: after the first few cells nobody has a new record to report)
+        if (usable && nIter > L.noList[4]) atomicMax(&L.noList[4], nIter);
+        if (P.pad0 & 2097152) { atomicAdd(&L.noList[8], nIter); atomicAdd(&L.noList[9], T); atomicAdd(&L.noList[10], nthis); }      // measurement aid (slow)
+        if (!usable) { atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); atomicAdd(&L.noList[6], 1); }
+    }
+}
+
+// the step that rebuilds the cells: candidates and pair lists of every cell (no forces; k_pair_list follows)
+inline void launch_build_lists(const StepParams& P, const int32_t* cellStart, hipStream_t stream, PairRange R, PairLists L)
+{
+    pair_range_default(P, R);
+    if (R.n == 0) return;
+    const BuildLds G(L.candLds, L.iterLds);
+    hipLaunchKernelGGL(k_build_lists, dim3(pair_range_grid(R.n)), dim3(kWave), G.bytes(), stream, P, cellStart, R.first, R.n, L);
+}
+inline size_t build_lists_lds_bytes(const PairLists& L) { return BuildLds(L.candLds, L.iterLds).bytes(); }
+
 template <int MODE, int VDW>
 inline void launch_pair_list_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
                                 int maxBlocks, hipStream_t stream, PairRange R, PairLists L, NextStep N, bool energies)
 {
+    const size_t lds = pair_list_lds_bytes(P, L);
     if (energies)
-        hipLaunchKernelGGL((k_pair_list<MODE, VDW, true>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
+        hipLaunchKernelGGL((k_pair_list<MODE, VDW, true>), dim3(pair_range_grid(R.n)), dim3(kWave), lds, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
                            cnt, R.blockBase, L, N);
     else
-        hipLaunchKernelGGL((k_pair_list<MODE, VDW, false>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
+        hipLaunchKernelGGL((k_pair_list<MODE, VDW, false>), dim3(pair_range_grid(R.n)), dim3(kWave), lds, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
                            cnt, R.blockBase, L, N);
 }
 

@@ -15,8 +15,8 @@
 //     bit-reproducible; each pair visit books half of the pair energy;
 //   * workgroup -> cell mapping keeps each XCD on a contiguous eighth of the cell list (private L2 per XCD).
 // One matrix instruction: the distance filter of pass 1 (v_mfma_f32_16x16x4_f32 as a 256-wide comparator, tile_filter); the potential is vector fp64.
-// Three roles (template parameters of k_pair_tile): the force kernel of runs that rebuild their cells every step; the list-building launch of the lazy
-// re-sort (BUILD: no forces - candidates and per-atom pair lists for k_pair_list, pair_list.hip.h); the clean-up launch behind k_pair_list (CLEANUP).
+// Two roles (template parameter of k_pair_tile): the force kernel of runs that rebuild their cells every step, and the clean-up launch behind
+// k_pair_list (CLEANUP; pair_list.hip.h holds the list kernel and the kernel that builds its lists).
 #pragma once
 #include "kernels.hip.h"
 
@@ -77,17 +77,6 @@ constexpr int kPairTabStride = 8;   // {p0..p4, r2cut, kqq, potential type} per 
                                     // kernels sit at 10 192 B of LDS, and 10 240 B is the limit for 16 waves per CU (+64 B cost 7 %)
 constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-Jones / charge-product table in LDS
 
-// Pair lists of the lazy re-sort (pair_list.hip.h).  The step that rebuilds the cells records, next to the candidates of every cell's tile, WHICH of them
-// each atom of the cell interacts with: every candidate within rc + 2 slack - until the next rebuild no atom moves farther than the slack, so no pair inside rc
-// can be missing.  The entries of one atom are dealt round-robin to the lanes (slices) that serve it, so on the plain steps all lanes of a wave run the same
-// number of iterations (+-1) instead of max-over-lanes of a random split.  An entry is the candidate's BYTE offset in the LDS tile (index * 8 < 2^16).
-// Layout per cell: chunks of 8 iterations; chunk c holds, for lane l, the 8 entries of iterations 8c .. 8c+7 as 16 contiguous bytes at (c * 64 + l) * 16, so a
-// wave reads a chunk as one coalesced 1 KiB load.
-constexpr int kListIters = 32;                       // iterations (entries per lane) a cell's list can hold; a cell that needs more keeps no list
-constexpr int kListStride16 = kListIters * kWave;   // uint16 entries per cell
-constexpr uint32_t kListDummy = (uint32_t)(kTileLds - 1) * 8u;          // entry of "no candidate": the last slot of the LDS tile (candidates fill slots < kTileCap)
-constexpr uint32_t kListDummy2 = kListDummy | (kListDummy << 16);
-
 // One pair visit of the specialised tile kernels: potential + electrostatics of the pair (i, candidate) at separation (dx, dy, dz), r2 = |d|^2.
 // `live` = the lane really has a candidate (only the unmasked Coulomb forms of tile_passes pass false).  Shared by the staging kernel below and
 // by the pair-list kernel (pair_list.hip.h), so both evaluate a pair with exactly the same operations.
@@ -116,7 +105,8 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
         // are pushed out to a huge r2, where sr6 underflows to exactly 0 and with it energy and force.
         // The exact cut-off test and the self pair also go through the EXEC mask: the filter is conservative by 1e-5, so next to the
         // atom's own copy (one hit in ~57) practically every lane passes and nothing diverges
-        if ((r2 > 0.0) & (r2 <= lj.r2cut))
+        // (MASKED = the list kernel: an atom is never on its own list and idle lanes never meet the dummy candidate at r = 0, so r^2 > 0 needs no test)
+        if ((MASKED || r2 > 0.0) & (r2 <= lj.r2cut))
         {
             const double r2i = fast_rcp(r2);
             const double sr2 = lj.p1 * r2i;
@@ -378,87 +368,31 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
     if (MODE != 0) acc.dropped += 0.5 * (double)nDropHalf;     // dropped pairs, counted per lane in "half pair" units (every pair is visited from both ends)
 }
 
-// Making the pair lists (the BUILD instantiation of k_pair_tile, on the step that rebuilds the cells): the distance filter of pass 1 with the LIST radius
-// rc + 2 slack, then every atom's hits are dealt round-robin to the lanes that serve it.  Geometry only - independent of the potential set.
-template <int LG>
-__device__ __forceinline__ void deal_hits(const double* tx, const double* ty, const double* tz, const float* tw, uint4* tlist, int T, int slice, double xi, double yi,
-                                          double zi, float filtB, double r2List, int kSelf, int& nMine, int& overflow)
-{
-    constexpr int NS = kWave >> LG;
-    constexpr int NR = (LG == 4) ? 1 : (LG == 5 ? 2 : 4);         // rounds of 96 candidates per lane that cover a full tile (320 / NS per lane)
-    const int lane = threadIdx.x & (kWave - 1);
-    const int il = lane & ((1 << LG) - 1);
-    const int iters = ((T + NS - 1) / NS + 3) & ~3;
-    // phase A: all distance tests; the hit masks of the whole tile stay in registers
-    uint32_t mm[3 * NR];
-#pragma unroll
-    for (int r = 0; r < NR; r++)
-    {
-        uint32_t m[4] = {0u, 0u, 0u, 0u};
-        if (r * 96 < iters) tile_filter<LG, kTileLds, 3>(tx, ty, tz, tw, r * 96, iters, slice, xi, yi, zi, filtB, r2List, m);
-        mm[3 * r] = m[0]; mm[3 * r + 1] = m[1]; mm[3 * r + 2] = m[2];
-    }
-    // the atom itself is a candidate of its own tile (kSelf, always a hit): not a partner - one entry less per atom
-    if (kSelf >= 0 && (kSelf & (NS - 1)) == slice)
-    {
-        const int c = kSelf >> (6 - LG);                       // its number among this lane's candidates
-#pragma unroll
-        for (int w = 0; w < 3 * NR; w++)
-            if ((c >> 5) == w) mm[w] &= ~(0x80000000u >> (c & 31));
-    }
-    // phase B: the tile is no longer needed - the list is assembled in its place.  Entries nobody writes point at the tile's last slot, which never holds
-    // a candidate: k_pair_list parks a far-away dummy there, so a lane whose list is shorter than the wave's needs no test of its own - it walks on over
-    // dummies, which fail the cut-off test like any candidate outside rc (and the read one candidate ahead is always a valid one)
-    __builtin_amdgcn_wave_barrier();
-    const uint4 zero4 = {kListDummy2, kListDummy2, kListDummy2, kListDummy2};
-    for (int q = lane; q < kListStride16 / 8; q += kWave) tlist[q] = zero4;
-    __builtin_amdgcn_wave_barrier();
-    uint16_t* const tl = (uint16_t*)tlist;
-    // where this lane's hits go in its atom's list: behind those of the lower slices
-    int h = 0;
-#pragma unroll
-    for (int w = 0; w < 3 * NR; w++) h += __popc(mm[w]);
-    int below = 0, total = 0;
-#pragma unroll
-    for (int q = 0; q < NS; q++)
-    {
-        const int hq = __shfl(h, il | (q << LG), kWave);
-        below += (q < slice) ? hq : 0;
-        total += hq;
-    }
-    int e = below;
-#pragma unroll
-    for (int w = 0; w < 3 * NR; w++)
-    {
-        uint32_t cur = mm[w];
-        const int kbase = 32 * w * NS + slice;                 // tile index of bit 31 of this word
-        while (cur != 0u)
-        {   // entry e of the atom's list -> slice e mod NS, iteration e / NS ; an entry is the candidate's byte offset in the LDS tile
-            const int b = __clz(cur);
-            cur &= ~(0x80000000u >> b);
-            const int k = kbase + b * NS;
-            const int t = e >> (6 - LG);
-            const int dl = il | ((e & (NS - 1)) << LG);
-            if (t < kListIters) tl[((((t >> 3) << 6) + dl) << 3) + (t & 7)] = (uint16_t)(k << 3);
-            else overflow = 1;
-            e++;
-        }
-    }
-    nMine = total;
-}
-
-// Lists of the lazy re-sort, written by the recording launch of k_pair_tile and read by k_pair_list (pair_list.hip.h)
+// Lists of the lazy re-sort, written by k_build_lists and read by k_pair_list (both in pair_list.hip.h); the clean-up launch of k_pair_tile looks at the
+// headers to find the cells that keep no list.  Sizes are per engine (Engine::allocate sizes them from density, cut-off and skin; they grow when too
+// many cells turn out not to fit).
 struct PairLists
 {
-    uint32_t* cand = nullptr;      // [nCell][kTileCap]: atom index | image code << 26 of every candidate, in tile order; padded with valid entries to a multiple of 64
+    uint32_t* cand = nullptr;      // [nCell][candCap]: atom index | image code << 26 of every candidate, in tile order; padded with valid entries to a multiple of 64
     int32_t* meta = nullptr;       // [nCell][2]: {candidates T | list iterations << 12, cell coordinates lx | cy << 10 | cz << 20 (written once by the host)} ;
-                                   //          first word -1: this cell keeps no list (its stencil needs more than one tile, it holds more
-                                   //          than 64 atoms, or an atom has more partners than the list holds) - such cells are staged in full on every step
-    uint16_t* pairs = nullptr;     // [nCell][kListStride16]
-    uint8_t* laneCnt = nullptr;    // [nCell][64]: entries of every lane
+                                   //          first word -1: this cell keeps no list (more candidates than the tile holds, more than 64 atoms, or more
+                                   //          iterations than iterCap) - such cells are staged in full on every step by the clean-up launch
+    uint16_t* pairs = nullptr;     // [nCell][iterCap * 64]: chunks of 8 iterations x 64 lanes; an entry is the byte offset of the candidate's record in the LDS tile
+                                   //          of k_pair_list: candidate k sits in record k + 1, record 0 is the far-away dummy (entry 0 = "no candidate")
     int32_t* noList = nullptr;     // [0], [1]: cells recorded without a list / cells recorded since the host last looked ; [2]: cells without a list in the lists in force
-                                   //      (zeroed by the host before every recording launch)
+                                   //      (zeroed before every recording launch) ; [3], [4]: largest T / largest iteration count ever recorded ; [5], [6]: cells that did not
+                                   //      fit the tile / the list since the host last looked ; [8..10] statistics (debug)
+    int32_t candCap = 0;           // candidates per cell in `cand` (multiple of 64)
+    int32_t iterCap = 0;           // list iterations per cell in `pairs` (multiple of 8)
+    int32_t candLds = 0;           // candidates the LDS tiles of k_pair_list / k_build_lists hold (multiple of 64, <= candCap): sized by the engine from the largest T
+                                   //      seen, because LDS per wave is what bounds the occupancy of k_pair_list (7.7 KiB: 95 us, 10.8 KiB: 106 us on the 1 M-atom box)
+    int32_t iterLds = 0;           // iterations the builder's LDS list buffer holds (multiple of 8, <= iterCap)
+    int32_t recBytes = 0;          // bytes per LDS record in k_pair_list: 24 {x, y, z} or 32 {x, y, z, radius}
+    int32_t entryScale = 0;        // list entry of record n: n * entryScale (the record's byte offset, or its number in the table-driven modes)
+    const float4* rel = nullptr;   // [atoms] written by the sort: position relative to the centre of the atom's own cell (f32) + its cell's z index; what the builder stages
 };
+// does this cell walk its list?  (the same test in k_pair_list and in the clean-up launch: every cell is served by exactly one of them)
+__device__ __forceinline__ bool list_usable(const PairLists& L, int header) { return header >= 0 && (header & 0xFFF) <= L.candLds; }
 
 __device__ __forceinline__ int wave_max_int(int v)
 {
@@ -544,22 +478,16 @@ __device__ __forceinline__ void next_step_finish(const StepParams& P, const Next
     }
 }
 
-template <int MODE, int VDW, bool CLEANUP, bool BUILD = false>
+template <int MODE, int VDW, bool CLEANUP>
                       // MODE 0: generic (any mix, radii) ; 1: one species, Lennard-Jones only ; 2: <= 4 species, one potential family VDW, elec none|dir|Fennell ;
                       // 3: as 2 with the real-space term of the Ewald sum ; 4: one species, surk with thermostat radii (case study 2).
                       // CLEANUP: the clean-up launch behind k_pair_list - a small grid that strides over the cells and stages those without a list.
-                      // BUILD (instantiated once, <1, 1, false, true>; the step that rebuilds the cells): no forces - stage every cell as usual, record the
-                      // candidates its tile holds and make the pair lists from them; k_pair_list then computes that step's forces like any other's
 __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 1) void k_pair_tile(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase,
                                                      PairLists L, NextStep N, SplitArgs Z)
 {
-    constexpr bool REC = BUILD;
     constexpr bool onlyUnlisted = CLEANUP;           // (a template parameter: with the strided loop of the clean-up launch in it the full launch lost 7 %)
-    // BUILD: the candidates' list entries, written out in one piece when the cell is done (stored one by one while staging they cost 80 us on the 1 M-atom
-    // box: stores and loads share one in-order counter, so every group's loads waited for the last group's stores)
-    __shared__ uint32_t tent[BUILD ? kTileCap : 1];
     // lazy re-sort (Engine::step): an atom has left the slack of the cell it was sorted into - until the next sort the stencil reaches one cell
     // further (rare; Engine::lazy_allowed guarantees that the wider stencil still sees every cell through one image only)
     const bool widened = P.lazySlack2 > 0.0 && P.nranks == 1 && slack_violated(P, counts);     // (a slab rank has no ghost layers to widen into: Engine reports the violation)
@@ -610,7 +538,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 
     // has exactly one cell; the clean-up launch (a few workgroups that stride over all cells) takes those without a list - or, after a slack violation, all
     bool cleanupIdle = false;
     if (onlyUnlisted && !widened) cleanupIdle = L.noList[2] == 0;       // the last recording left no cell without a list: nothing to clean up
-    const int nSplit = (CLEANUP || BUILD) ? 1 : Z.n;
+    const int nSplit = CLEANUP ? 1 : Z.n;
     const int sub = (int)(blockIdx.x >> 3) & (nSplit - 1);           // which share of the stencil's columns this wave takes (all shares of a cell on one XCD)
     for (int rowBase = (int)(blockIdx.x >> 3) / nSplit; rowBase < per && !cleanupIdle; rowBase += CLEANUP ? kWave * rowStep : per)
     {
@@ -620,7 +548,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 
         const int myRow = rowBase + lane * rowStep;
         const int myCr = (blockIdx.x & 7) * per + myRow;
         bool need = myRow < per && myCr < nCellsRun;
-        if (!widened && need) need = L.meta[2 * (firstCell + myCr)] < 0;
+        if (!widened && need) need = !list_usable(L, L.meta[2 * (firstCell + myCr)]);
         todo = __ballot(need);
     }
     else if ((blockIdx.x & 7) * per + rowBase >= nCellsRun) todo = 0ULL;
@@ -648,22 +576,6 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 
             ext2 = w0 * w0 + w1 * w1 + w2 * w2;
         }
         const double filtThr = P.r2Max + 1.9073486328125e-06 * (4.0 * ext2 + P.r2Max);      // 2^-19
-        // Lists (lazy re-sort): on the step that rebuilds the cells the staging below also records WHICH atoms it kept (index + image code, in tile
-        // order) and, in the BUILD launch, which of them every atom of the cell interacts with (deal_hits); until the next rebuild the atoms keep their slots
-        // and nobody moves farther than the slack the pruning radius already allows for, so the plain steps run k_pair_list: no run table, no pruning,
-        // no compaction, no distance filter.  Cells whose stencil needs more than one tile or that hold more than 64 atoms keep no list.
-        uint32_t* const myList = L.cand + (size_t)cell * kTileCap;       // (only touched when recording)
-        const bool record = REC && !widened && (ie - ib) <= kWave;
-        if (BUILD)
-        {
-            if (blockIdx.x == 0 && lane == 0) atomicAdd(&L.noList[1], nCellsRun);      // cells recorded (one atomic per launch: one per cell on one address cost 650 us)
-            if (ie == ib) { if (lane == 0) L.meta[2 * cell] = 0; continue; }          // an empty cell: a list with nothing in it
-            if (!record)
-            {   // more than 64 atoms: the cell keeps no list
-                if (lane == 0) { L.meta[2 * cell] = -1; atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
-                continue;
-            }
-        }
         for (int i0 = ib; i0 < ie; i0 += kWave)
         {
             const int nthis = min(kWave, ie - i0);
@@ -687,14 +599,12 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 
             const float filtC = 0.0f;
             acc.fx = 0.0; acc.fy = 0.0; acc.fz = 0.0; acc.eV = 0.0; acc.eC = 0.0; acc.dropped = 0.0;
             int T = 0;
-            bool flushed = false;                              // the stencil did not fit the tile in one piece
             // one LDS chunk = two passes per round of 96 candidates per lane:
             //   pass 1  distance tests only (7 fp64 ops per candidate); hits are recorded in per-lane bit masks
             //   pass 2  every lane pops its own hits, so the expensive potential runs on densely filled waves
             //           (about 20 % of the candidates are inside the cut-off: evaluating the potential inline would
             //            execute it for nearly every wave-iteration with 80 % of the lanes masked off)
             auto process = [&]() {
-                if (BUILD) { T = 0; return; }                 // (tile full before the stencil is through: this cell will keep no list)
                 // far-away, FINITE dummies behind the last candidate: the passes need no bounds checks, and dead lanes have a
                 // harmless candidate to chew on (uninitialised LDS could hold NaN patterns: 0 * NaN would poison a force)
                 if (lane < kTilePad)
@@ -804,13 +714,12 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 
                             const bool keep = (lane < n0) && (bx * bx + by * by + bz * bz) <= P.pruneR2;
                             const unsigned long long mask = __ballot(keep);
                             const int nk = __popcll(mask);
-                            if (T + nk > kTileCap) { process(); flushed = true; continue; }
+                            if (T + nk > kTileCap) { process(); continue; }
                             if (keep)
                             {
                                 const int pp = T + lanes_below(mask);
                                 tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
                                 tw[pp] = -(float)(xj * xj + yj * yj + zj * zj);
-                                if (BUILD) tent[pp] = (uint32_t)j | ((uint32_t)code0 << 26);
                                 if (!kOneSpecies) ttyp[pp] = (uint8_t)typ0;
                                 if (MODE == 0 || MODE == 4) trad[pp] = rad0;
                             }
@@ -859,7 +768,6 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 
                                     const int pp = T + lanes_below(mask);
                                     tx[pp] = xj; ty[pp] = yj; tz[pp] = zj;
                                     tw[pp] = -(float)(xj * xj + yj * yj + zj * zj);
-                                    if (BUILD) tent[pp] = (uint32_t)(__builtin_amdgcn_readlane(vj, u) + lane) | ((uint32_t)gcode[u] << 26);
                                     if (!kOneSpecies) ttyp[pp] = (uint8_t)gtyp[u];
                                     if (MODE == 0 || MODE == 4) trad[pp] = grad[u];
                                 }
@@ -870,59 +778,6 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
-            }
-            if (BUILD)
-            {
-                bool usable = !flushed;
-                int nIter = 0;
-                if (usable)
-                {
-                    // the plain steps gather whole groups of 64 candidates: the last group is filled with a valid atom (the cell's first) - its copies land
-                    // behind the candidates any list entry points at
-                    const int Tpad = (T + kWave - 1) & ~(kWave - 1);
-                    for (int q = lane; q < Tpad; q += kWave) myList[q] = (q < T) ? tent[q] : ((uint32_t)ib | (0x15u << 26));
-                    if (lane < kTilePad) { tx[T + lane] = -1e30; ty[T + lane] = 0.0; tz[T + lane] = 0.0; tw[T + lane] = -3e38f; }     // dummies, as in process()
-                    __builtin_amdgcn_wave_barrier();
-                    // list radius rc + 2 slack (= the pruning radius of the tile); f32 threshold widened by the error bound like filtThr above
-                    const double thrList = P.pruneR2 + 1.9073486328125e-06 * (4.0 * ext2 + P.pruneR2);
-                    const float fB = (slice == 0) ? (float)(2.0 * xi) : (slice == 1) ? (float)(2.0 * yi) : (slice == 2) ? (float)(2.0 * zi)
-                                                                                     : (float)(thrList - (xi * xi + yi * yi + zi * zi));
-                    const double r2List = P.pruneR2 * (1.0 + 1e-13);
-                    int nMine = 0, overflow = 0;
-                    // where the cell's own atoms sit in the tile (they are candidates too, unshifted): found by their list entries
-                    for (int q = lane; q < T; q += kWave)
-                    {
-                        const uint32_t en = tent[q];
-                        const int rel = (int)(en & 0x3FFFFFFu) - ib;
-                        if ((en >> 26) == 0x15u && rel >= 0 && rel < nthis) entJ[rel] = q;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const int kSelf = validI ? entJ[il] : -1;
-                    uint4* const tlist = (uint4*)txyz;             // the list is assembled where the tile was
-                    static_assert(sizeof(double) * 3 * kTileLds >= sizeof(uint16_t) * kListStride16, "the list is assembled where the tile was");
-                    if (lg == 4) deal_hits<4>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, kSelf, nMine, overflow);
-                    else if (lg == 5) deal_hits<5>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, kSelf, nMine, overflow);
-                    else deal_hits<6>(tx, ty, tz, tw, tlist, T, slice, xi, yi, zi, fB, r2List, kSelf, nMine, overflow);
-                    __builtin_amdgcn_wave_barrier();
-                    const int ls = 6 - lg, ns = 1 << ls;                             // log2(slices), slices
-                    nIter = wave_max_int((nMine + ns - 1) >> ls);
-                    // (debug bit 65536, tests: lists hold 14 iterations only - on a liquid part of the cells then keep no list and go through the clean-up launch)
-                    usable = nIter <= ((P.pad0 & 65536) ? 14 : kListIters) && !__any(overflow != 0);
-                    if (usable)
-                    {
-                        L.laneCnt[(size_t)cell * kWave + lane] = (uint8_t)max(0, (nMine - slice + ns - 1) >> ls);
-                        uint4* const out = (uint4*)(L.pairs + (size_t)cell * kListStride16);
-                        for (int c = 0; c * 8 < nIter; c++) out[c * kWave + lane] = tlist[c * kWave + lane];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (lane == 0)
-                {
-                    L.meta[2 * cell] = usable ? (T | (nIter << 12)) : -1;
-                    if (P.pad0 & 2097152) { atomicAdd(&L.noList[3], nIter); atomicAdd(&L.noList[4], T); atomicAdd(&L.noList[5], nthis); }      // measurement aid (slow)
-                    if (!usable) { atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); }
-                }
-                continue;                                          // no forces here: k_pair_list computes them
             }
             process();
 
@@ -1001,7 +856,6 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 
         }
     }
     }   // batches of rows
-    if (BUILD) return;
     eV = wave_sum(eV); eC = wave_sum(eC); dropped = wave_sum(dropped);
     if (lane == 0)
     {
@@ -1045,16 +899,6 @@ inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const D
     else
         hipLaunchKernelGGL((k_pair_tile<MODE, VDW, false>), dim3(pair_range_grid(R.n) * Z.n), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, partials,
                            maxBlocks, cnt, R.blockBase, L, NextStep(), Z);
-}
-
-// the step that rebuilds the cells: candidates and pair lists of every cell (no forces; k_pair_list follows)
-inline void launch_build_lists(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, hipStream_t stream,
-                               PairRange R, PairLists L)
-{
-    pair_range_default(P, R);
-    if (R.n == 0) return;
-    hipLaunchKernelGGL((k_pair_tile<1, 1, false, true>), dim3(pair_range_grid(R.n)), dim3(kWave), 0, stream, P, S, pots, A, cellStart, R.first, R.n, (double*)nullptr, 0, cnt,
-                       0, L, NextStep(), SplitArgs());
 }
 
 // dispatch on the potential set.  P.pad1 == 2: every defined pair potential belongs to the family P.vdwFamily (1 lnjs, 2 buck, 3 p746, 4 bmhs; 5 = a mix of

@@ -247,6 +247,14 @@ def config(name):
         return lj_case((63, 63, 63), seed=20240502, charges=(0.2, -0.2), elec="fenn")
     if name == "C4":      # 1 000 188 atoms, pure LJ
         return lj_case((63, 63, 63), seed=20240502)
+    if name == "C4T":     # C4 thermalised: Maxwell velocities at argon's 85 K (`init_vel gaus` state; the reference's cost does not depend on temperature, ours does)
+        return lj_case((63, 63, 63), seed=20240502, vel_T=85.0)
+    if name == "C3T":     # C3 thermalised at 85 K
+        return lj_case((63, 63, 63), seed=20240502, charges=(0.2, -0.2), elec="fenn", vel_T=85.0)
+    if name == "C2T":     # C2 thermalised at 85 K (small twin of C4T for parity tests)
+        return lj_case((20, 20, 25), seed=20240501, vel_T=85.0)
+    if name == "C4X":     # C4's lattice in a box that is an exact multiple of the cut-off (42 x 8.5 A): no accidental overhang of the cells over rc
+        return lj_case((63, 63, 63), a=42 * 8.5 / 63, seed=20240502)
     if name == "C1":      # synthetic twin of 'case study 1': 40 000 Ar gas atoms in a 1141.5 A box, LJ rc 4 A, cell_list 85 A, radiative thermostat
         rng = np.random.Generator(np.random.PCG64(20240506))
         N, L = 40000, 1141.5

@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--pair-variant", type=int, default=0)
     ap.add_argument("--cell-size", type=float, default=0.0)
     ap.add_argument("--sort-every", type=int, default=0, help="cell-list rebuild schedule: 0 adaptive lazy re-sort (default), 1 every step (the reference's), n at most every n-th step")
+    ap.add_argument("--skin", type=float, default=0.0, help="Verlet skin in A (0: automatic, < 0: none - cells exactly as control.cell_list gives them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU baseline sample (0: sized for ~15 s)")
     ap.add_argument("--debug", type=int, default=0,
@@ -142,7 +143,7 @@ def main():
     transport = "single GPU"
     try:
         eng = api.Engine(model, device=local_rank, initial_forces=1, pair_variant=a.pair_variant, cell_size=a.cell_size,
-                         use_graph=0 if a.no_graph else 1, profile=0, slab=slab, debug=a.debug, sort_every=a.sort_every, split=a.split)
+                         use_graph=0 if a.no_graph else 1, profile=0, slab=slab, debug=a.debug, sort_every=a.sort_every, split=a.split, skin=a.skin)
         if world > 1:
             transport = "RCCL send/recv over xGMI"
         if a.emulate_ranks > 1:

@@ -118,32 +118,38 @@ typedef struct
     const int32_t *angle_c, *angle_l1, *angle_l2, *angle_type;
 } aztot_bonded;
 
-/* run-time switches that replace the reference's compile-time defines.h and its two mains' differences */
+/* run-time switches that replace the reference's compile-time defines.h (defines.h:5-23) and the kernel-launch file cuda.txt (cuInit.cu:701-749),
+   and settle the differences between the reference's two mains.  Always start from aztot_default_options(): it fills struct_size, and a
+   library that is handed a struct of another size refuses it (AZTOT_ERR_ARG) instead of reading fields that are not there.
+   Measurement switches (A/B comparisons of kernel paths, phase timing) are NOT part of this struct: they are read from the environment variable
+   AZTOT_DEBUG when a device handle is created (a bit mask; the bits are listed in aztotmd_amd/csrc/engine.h, enum DebugBit). */
 typedef struct
 {
+    uint32_t struct_size;        /* sizeof(aztot_options) of the caller, set by aztot_default_options */
     int32_t device;              /* HIP device ordinal (reference: device 0 hard-coded, cuInit.cu:688) */
     int32_t initial_forces;      /* 1: forces of the initial configuration are computed at init (serial path,
                                        sys_init.cpp:1181-1184); 0: start from F = 0 (GPU path, sys_init.cpp:551-553) */
     int32_t center_box;          /* 1: apply center_box at init (serial path only, sys_init.cpp:1145) */
     uint64_t seed;               /* seed of the counter-based RNG (thermostat, tables, init_vel) */
-    int32_t pair_variant;        /* 0: auto (= 2 where the geometry allows, else 1); 1: per-atom gather kernel; 2: LDS-tiled wave-per-cell kernel;
+    int32_t pair_variant;        /* 0: auto (= 2 where the geometry allows, else 1); 1: per-atom gather kernel; 2: LDS-tiled wave-per-cell kernels (+ pair lists);
                                     3: four waves share a tile of 16-atom cell bins (opt-in: slower than 2 on MI355X) */
-    double cell_size;            /* 0: derive from control.cell_list / cut-off; >0: force this cell edge */
+    double cell_size;            /* 0: derive from control.cell_list / cut-off (+ skin); >0: force this cell edge */
     int32_t use_graph;           /* 1: replay the step as a captured hipGraph when possible */
     int32_t profile;             /* 1: time every kernel with HIP events (aztot_kernel_times) */
-    int32_t reserved[8];         /* [0]: path switches for A/B measurements, results unchanged (128: k_integrate2 every step, 256: large-system
-                                    kick path, 512: generic pair kernel, 4096: hipGraph replay of a loopback slab rank, 8192: lazy re-sort at the fixed interval reserved[2] whatever the atoms' speed -
-                                    exercises the wider-stencil fallback, 16384: slab ranks run the coordinate exchange of plain steps on a second stream beside the interior cells' pair forces - measured slower,
-                                    32768: no pair lists (the steps between two rebuilds stage every cell), 65536: pair lists capped at 14 iterations (part of a liquid's cells then goes through the
-                                    clean-up launch), 131072 / 262144: next-step fusion off / on whatever the system size, 524288: plain steps check every atom against its reference position (no displacement bound),
-                                    2097152: list statistics on stderr with AZTOT_VERBOSE, 4194304: second half-kick and radiative thermostat as two launches, 8388608: hipGraph replay also above 500 000 atoms, 16777216: plain steps integrate one atom per thread, 33554432: thermostat runs close a step and open the next in two launches, 67108864: one wave per cell in the staging kernel whatever the system,
-                                    134217728: the list kernel books pair energies on every step, not only on the last step of a call) - and one that is NOT
-                                    result-preserving: 2048 = the pair kernel stages its tile and stops (phase timing only);
-                                    [1]: 1 = loopback slab transport (one rank of N talks to itself: timing aid);
-                                    [3]: waves per cell in the staging pair kernel, 1 / 2 / 4 / 8 forced (0, default: the engine decides - several where cells are few or stencils wide);
-                                    [2]: cell-list rebuild schedule on one GPU.  0 (default): adaptive - a step re-sorts only when an atom could have left the
-                                    slack between the stencil's reach and the cut-off (exact; the reference rebuilds every step, main.cu:300-326, and results then
-                                    differ from an every-step run in summation order only); 1: every step; n > 1: adaptive, at most every n-th step */
+    int32_t sort_every;          /* cell-list rebuild schedule.  0 (default): adaptive - the cells are rebuilt only when an atom could have used up its
+                                    share of the skin (exact; the reference rebuilds every step, main.cu:300-326, and results then differ from an
+                                    every-step run in summation order only); 1: every step, the reference's schedule; n > 1: adaptive, at most every n-th step */
+    double skin;                 /* Verlet skin in Angstrom: the pair lists hold every pair within cut-off + skin, an atom may move skin / 2 between two rebuilds.
+                                    0 (default): automatic (about 4 % of the cut-off; cells are sized cut-off + skin when control.cell_list asks for cells
+                                    of about the cut-off); > 0: this value; < 0: no skin - cells exactly as control.cell_list / split_cells
+                                    (cuCellList.cu:9-34) give them, the slack is whatever the cell edge happens to overhang the cut-off */
+    int32_t waves_per_cell;      /* staging pair kernel: waves that share one cell's stencil, 1 / 2 / 4 / 8 (0, default: the engine decides - several where
+                                    cells are few or stencils wide) */
+    int32_t energies_every_step; /* 1: pair energies are booked on every step (0, default: only on the last step of an aztot_step call, the only one whose
+                                    statistics the caller can see; forces and trajectories are bit-identical either way) */
+    int32_t loopback_ranks;      /* measurement aid for aztot_init_device_slab without a transport: 1 = this rank exchanges its halo with itself
+                                    (one rank of N on one GPU; never a result) */
+    int32_t reserved[5];         /* must be zero */
 } aztot_options;
 
 /* per-step scalars: the fields tracked by stat.dat (cuStat.cu:241-261) + serial calc_chars (integrators.cpp:63-73) */
