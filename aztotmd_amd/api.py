@@ -11,7 +11,7 @@ _LIB = None
 
 STAT_FIELDS = ("step", "time", "engTot", "engKin", "engVdW", "engCoul", "engElecField", "engTemp", "engPot", "temperature",
                "posMom", "negMom", "posCross", "negCross", "pressure", "pairs_dropped", "n_cells", "nose_chit", "nose_conint",
-               "engBond", "engAngle", "engCoulRec", "engCoulConst", "sort_interval", "sort_violations", "pair_lists", "cells_without_list")
+               "engBond", "engAngle", "engCoulRec", "engCoulConst", "sort_interval", "sort_violations", "pair_lists", "cells_without_list", "rebuilds", "skin")
 
 
 class AztotError(RuntimeError):
@@ -76,7 +76,11 @@ class _Stats(C.Structure):
                 ("negCross", C.c_int64 * 3), ("pressure", C.c_double), ("pairs_dropped", C.c_int64), ("n_cells", C.c_int64),
                 ("nose_chit", C.c_double), ("nose_conint", C.c_double), ("engBond", C.c_double), ("engAngle", C.c_double),
                 ("engCoulRec", C.c_double), ("engCoulConst", C.c_double), ("sort_interval", C.c_int64), ("sort_violations", C.c_int64),
-                ("pair_lists", C.c_int64), ("cells_without_list", C.c_int64)]
+                ("pair_lists", C.c_int64), ("cells_without_list", C.c_int64), ("rebuilds", C.c_int64), ("skin", C.c_double)]
+
+
+class _Clock(C.Structure):
+    _fields_ = [("step", C.c_int64), ("nose_chit", C.c_double), ("nose_conint", C.c_double), ("eng_kin", C.c_double)]
 
 
 class _State(C.Structure):
@@ -86,9 +90,9 @@ class _State(C.Structure):
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
 
-EXPORTS = ("aztot_device_count", "aztot_init_md", "aztot_model_create", "aztot_model_set_bonded", "aztot_model_query", "aztot_model_species_name", "aztot_free_md", "aztot_default_options",
+EXPORTS = ("aztot_device_count", "aztot_device_synchronize", "aztot_init_md", "aztot_model_create", "aztot_model_set_bonded", "aztot_model_query", "aztot_model_species_name", "aztot_free_md", "aztot_default_options",
            "aztot_init_device", "aztot_free_device", "aztot_step", "aztot_forces", "aztot_get_stats", "aztot_species_crossings", "aztot_md_to_host",
-           "aztot_set_state", "aztot_cell_table", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id", "aztot_comm_selftest", "aztot_comm_ranks",
+           "aztot_set_state", "aztot_get_clock", "aztot_set_clock", "aztot_cell_table", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id", "aztot_comm_selftest", "aztot_comm_ranks",
            "aztot_init_device_slab", "aztot_last_error", "aztot_version")
 
 
@@ -139,6 +143,8 @@ def lib():
         L.aztot_species_crossings.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
         L.aztot_md_to_host.argtypes = [C.c_void_p, C.POINTER(_State)]
         L.aztot_set_state.argtypes = [C.c_void_p, C.POINTER(_State)]
+        L.aztot_get_clock.argtypes = [C.c_void_p, C.POINTER(_Clock)]
+        L.aztot_set_clock.argtypes = [C.c_void_p, C.POINTER(_Clock)]
         L.aztot_cell_table.argtypes = [C.c_void_p, _ip, _ip, C.c_int, _ip, C.c_int]
         L.aztot_kernel_times.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.POINTER(C.c_int64), C.c_int]
         L.aztot_reset_kernel_times.argtypes = [C.c_void_p]
@@ -383,6 +389,16 @@ class Engine:
             setattr(st, k, a.ctypes.data_as(_dp))
         _check(lib().aztot_set_state(self.h, C.byref(st)))
 
+    def clock(self):
+        """step number + thermostat scalars: with state() everything a restart needs (aztot_clock)"""
+        c = _Clock()
+        _check(lib().aztot_get_clock(self.h, C.byref(c)))
+        return {"step": c.step, "nose_chit": c.nose_chit, "nose_conint": c.nose_conint, "eng_kin": c.eng_kin}
+
+    def set_clock(self, step, nose_chit=0.0, nose_conint=0.0, eng_kin=0.0):
+        c = _Clock(int(step), float(nose_chit), float(nose_conint), float(eng_kin))
+        _check(lib().aztot_set_clock(self.h, C.byref(c)))
+
     def cell_table(self):
         """(dims, cell_start[n_cells + 1], atom_id[resident atoms]) of the sorted cell list the device holds."""
         dims = np.zeros(3, dtype=np.int32)
@@ -427,6 +443,11 @@ def device_count():
     """HIP devices visible to this process (through libaztot, i.e. the system ROCm runtime: importing torch into a process that later
     brings up RCCL would put torch's bundled, un-initialised HSA copy in front of it)."""
     return int(lib().aztot_device_count())
+
+
+def device_synchronize(device=0):
+    """hipDeviceSynchronize through libaztot (the bracket of a timed region; no torch needed in the process)"""
+    _check(lib().aztot_device_synchronize(int(device)))
 
 
 def rccl_unique_id():

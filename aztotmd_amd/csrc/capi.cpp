@@ -186,6 +186,14 @@ int aztot_device_count(void)
     return n < 0 ? 0 : n;
 }
 
+int aztot_device_synchronize(int device)
+{
+    return guarded([&] {
+        check_hip(hipSetDevice(device), "hipSetDevice");
+        check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    });
+}
+
 void aztot_default_options(aztot_options* opt)
 {
     if (!opt) return;
@@ -287,6 +295,18 @@ int aztot_set_state(aztot_md* md, const aztot_state* in)
 {
     if (!md || !in) return fail(AZTOT_ERR_ARG, "null argument");
     return guarded([&] { md->eng->set_state(*in); });
+}
+
+int aztot_get_clock(aztot_md* md, aztot_clock* out)
+{
+    if (!md || !out) return fail(AZTOT_ERR_ARG, "null argument");
+    return guarded([&] { md->eng->get_clock(*out); });
+}
+
+int aztot_set_clock(aztot_md* md, const aztot_clock* in)
+{
+    if (!md || !in) return fail(AZTOT_ERR_ARG, "null argument");
+    return guarded([&] { md->eng->set_clock(*in); });
 }
 
 int aztot_cell_table(aztot_md* md, int32_t dims[3], int32_t* cell_start, int cap_cells, int32_t* atom_id, int cap_atoms)

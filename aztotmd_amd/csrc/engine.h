@@ -68,6 +68,8 @@ public:
     void species_crossings(int64_t* out, int cap);
     void md_to_host(aztot_state& out);
     void set_state(const aztot_state& in);
+    void get_clock(aztot_clock& out);
+    void set_clock(const aztot_clock& in);
     int cell_table(int32_t dims[3], int32_t* cellStart, int capCells, int32_t* atomId, int capAtoms);
     int kernel_times(std::vector<KernelTimer>& out);
     void reset_kernel_times();
@@ -143,6 +145,7 @@ private:
     double lazyMargin_ = 1.5;          // one GPU: K steps of the longest step seen may use slack / lazyMargin_; widened by every violation (a system that heats up)
     bool lazyMeasured_ = false;     // the interval has been sized from a measurement at least once
     int sinceSort_ = 1 << 30;       // plain steps since the last sort
+    long long rebuilds_ = 0;        // steps that rebuilt the cell list so far
     double lazySlack_ = 0.0;
     RefPos ref_{};
     // lists of the lazy re-sort (pair_tile.hip.h / pair_list.hip.h), recorded by the step that rebuilds the cells and walked by the plain steps: per cell the
@@ -170,6 +173,8 @@ private:
     hipEvent_t evHaloInfo_ = nullptr;
     bool haloInfoPending_ = false;
     void take_halo_info();
+    void post_count_exchange();
+    void adopt_halo_info(const int32_t* h);
     int graphCycle_ = 0;            // steps held by the captured graphs
     CellBins bins_{};               // per-cell bins of 16 atoms for pair kernel 3 (all-null when that kernel cannot run)
     BondedTables bonded_{};         // all-null when the model has no bonds / angles

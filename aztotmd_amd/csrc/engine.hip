@@ -472,8 +472,8 @@ void Engine::allocate()
     if (nranks_ > 1)
     {
         for (int k = 0; k < 4; k++) { dMsg_[k] = (char*)alloc(lay_.bytes()); HIP_CHECK(hipMemsetAsync(dMsg_[k], 0, lay_.bytes(), stream_)); }
-        dHaloInfo_ = (int32_t*)alloc(sizeof(int32_t) * 8);
-        HIP_CHECK(hipMemsetAsync(dHaloInfo_, 0, sizeof(int32_t) * 8, stream_));
+        dHaloInfo_ = (int32_t*)alloc(sizeof(int32_t) * 16);
+        HIP_CHECK(hipMemsetAsync(dHaloInfo_, 0, sizeof(int32_t) * 16, stream_));
     }
     const int ns = model_.nSpec();
     std::vector<DevPot> pots((size_t)ns * ns);
@@ -936,8 +936,32 @@ void Engine::take_halo_info()
 {
     if (!haloInfoPending_) return;
     HIP_CHECK(hipEventSynchronize(evHaloInfo_));
-    halo_[0] = hHalo_[2]; halo_[1] = hHalo_[0]; halo_[2] = hHalo_[1]; halo_[3] = hHalo_[3]; halo_[4] = hHalo_[4];
     haloInfoPending_ = false;
+    adopt_halo_info(hHalo_);
+}
+
+// Behind every sort that opens an interval of plain steps the ranks tell each other how many boundary atoms they will send per plain step (k_rank_gather
+// left {send count, ghost count} per side in dHaloInfo_[5..6] and [10..11]); the right neighbour's pair lands in [12..13], the left one's in [14..15].
+// Fixed-size messages: this exchange cannot itself be mismatched.
+void Engine::post_count_exchange()
+{
+    const int left = (rank_ + nranks_ - 1) % nranks_, right = (rank_ + 1) % nranks_;
+    xch_->exchange_counts(left, right, dHaloInfo_ + 5, dHaloInfo_ + 10, dHaloInfo_ + 14, dHaloInfo_ + 12, 2, stream_);
+}
+
+// ... and before the first plain step posts a send or a receive, every rank checks that its ghost ranges are exactly as long as what the neighbours
+// will send: a disagreement (a protocol error - the ranges are equal by construction) is reported as an error instead of hanging in RCCL or silently
+// shifting coordinates onto the wrong atoms
+void Engine::adopt_halo_info(const int32_t* h)
+{
+    halo_[0] = h[2]; halo_[1] = h[0]; halo_[2] = h[1]; halo_[3] = h[3]; halo_[4] = h[4];
+    const int ghostsLeft = h[2], ghostsRight = h[4] - h[3], sendLeft = h[5], sendRight = h[10];
+    // (both ranks of a boundary evaluate the same two equalities, so they fail together)
+    if (h[12] != ghostsRight || h[13] != sendRight || h[14] != ghostsLeft || h[15] != sendLeft)
+        throw std::runtime_error("slab decomposition: the neighbours disagree about their boundary atoms (left boundary: this rank sends " + std::to_string(sendLeft) +
+                                 " and holds " + std::to_string(ghostsLeft) + " ghosts, the neighbour holds " + std::to_string(h[15]) + " and sends " + std::to_string(h[14]) +
+                                 "; right boundary: sends " + std::to_string(sendRight) + ", holds " + std::to_string(ghostsRight) + ", the neighbour holds " +
+                                 std::to_string(h[13]) + " and sends " + std::to_string(h[12]) + "): no coordinate exchange was posted");
 }
 
 // one message to each x-neighbour: migrants + halo (packed by k_integrate1_bin; protocol in slab.hip.h)
@@ -1041,16 +1065,18 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
     });
     cur_ ^= 1;
     sinceSort_ = 0;
+    if (!capturing_ && stepMode == 1) rebuilds_++;
     listsValid_ = false;            // (until this step's launch_pair records them)
     if (nranks_ > 1 && lazyOn_ && lazyK_ > 1)
     {   // where the boundary layers sit in the sorted arrays: [ownedBegin, end of layer 2hw-1) goes left, [start of layer ncx-2hw, ownedEnd) goes right;
         // ghosts are [0, ownedBegin) and [ownedEnd, nTotal).  One small read-back per sort.
         if (!hHalo_)
         {
-            HIP_CHECK(hipHostMalloc((void**)&hHalo_, sizeof(int32_t) * 8, hipHostMallocDefault));
+            HIP_CHECK(hipHostMalloc((void**)&hHalo_, sizeof(int32_t) * 16, hipHostMallocDefault));
             HIP_CHECK(hipEventCreateWithFlags(&evHaloInfo_, hipEventDisableTiming));
         }
-        HIP_CHECK(hipMemcpyAsync(hHalo_, dHaloInfo_, sizeof(int32_t) * 5, hipMemcpyDeviceToHost, stream_));
+        post_count_exchange();
+        HIP_CHECK(hipMemcpyAsync(hHalo_, dHaloInfo_, sizeof(int32_t) * 16, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipEventRecord(evHaloInfo_, stream_));
         haloInfoPending_ = true;      // (no stall here: take_halo_info waits when the numbers are needed)
     }
@@ -1193,7 +1219,7 @@ void Engine::step(int nsteps)
         {
             sync();
             adapt_sort_interval();
-            lazyWindow_ = std::min(256, 2 * lazyWindow_);
+            lazyWindow_ = std::min(nranks_ > 1 ? 64 : 256, 2 * lazyWindow_);     // (slab ranks cannot repair a slack violation, only report it: they look more often)
         }
     }
     kickOwed_ = lazyKick_;          // set here, not in launch_step_kernels: a replayed graph does not pass through the host code
@@ -1289,6 +1315,7 @@ void Engine::run_steps(int nsteps)
             GraphSlot* slot = graph_for_state(cycle);
             HIP_CHECK(hipGraphLaunch(slot->exec, stream_));
             done += cycle;
+            rebuilds_ += (lazyOn_ && lazyK_ > 1) ? 1 : cycle;       // (a captured cycle: one sort interval, or two every-step steps)
             set_buf_state(slot->after);           // one sort per cycle (K > 1) and the coordinate-array swaps of the fused steps
             sinceSort_ = 1 << 30;                 // the next cycle (or the eager remainder) starts with a sort
         }
@@ -1320,10 +1347,12 @@ void Engine::prepare_next_call()
         }
         if (nranks_ > 1)
         {   // the plain steps' coordinate exchange needs to know where the boundary layers sit; with interval 1 nobody had asked (k_rank_gather left it ready)
-            int32_t h[5];
+            int32_t h[16];
+            post_count_exchange();
+            HIP_CHECK(hipStreamSynchronize(stream_));
             HIP_CHECK(hipMemcpy(h, dHaloInfo_, sizeof(h), hipMemcpyDeviceToHost));
-            halo_[0] = h[2]; halo_[1] = h[0]; halo_[2] = h[1]; halo_[3] = h[3]; halo_[4] = h[4];
             haloInfoPending_ = false;
+            adopt_halo_info(h);
         }
         listsValid_ = true;
     }
@@ -1500,6 +1529,8 @@ void Engine::get_stats(aztot_stats& out)
     out.nose_chit = s.chit; out.nose_conint = s.conint;
     out.sort_interval = lazyOn_ ? lazyK_ : 1; out.sort_violations = lazyViolations_;
     out.pair_lists = (listsOn_ && lazyOn_ && lazyK_ > 1) ? 1 : 0;
+    out.rebuilds = rebuilds_;
+    out.skin = 2.0 * lazySlack_;
     out.cells_without_list = 0;
     if (listsOn_)
     {
@@ -1574,6 +1605,28 @@ void Engine::md_to_host(aztot_state& out)
         for (int k = 0; k < n; k++) out.types[ids[k]] = ty[k];
     }
     out.n_atoms = n;   // number of atoms this rank wrote
+}
+
+// restart support: step number + thermostat scalars (see aztot_clock)
+void Engine::get_clock(aztot_clock& out)
+{
+    sync();
+    DevStats s;
+    HIP_CHECK(hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost));
+    out.step = s.step; out.nose_chit = s.chit; out.nose_conint = s.conint; out.eng_kin = s.ekSim;
+}
+
+void Engine::set_clock(const aztot_clock& in)
+{
+    sync();
+    DevStats s;
+    HIP_CHECK(hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost));
+    s.step = in.step; s.stepAtSort = in.step; s.chit = in.nose_chit; s.conint = in.nose_conint; s.ekSim = in.eng_kin; s.engKin = in.eng_kin;
+    s.pendingKick = 0;
+    HIP_CHECK(hipMemcpy(dStats_, &s, sizeof(DevStats), hipMemcpyHostToDevice));
+    lastPresStep_ = in.step;
+    sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false;       // the next call rebuilds the cells
+    destroy_graphs();
 }
 
 // read-back of the sorted cell list (cudaMD::firstAtomInCell + the id of the atom in every slot)

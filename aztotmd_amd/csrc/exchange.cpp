@@ -61,6 +61,24 @@ void CallbackExchanger::exchange_ranges(int left, int right, double* const* arra
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
+void CallbackExchanger::exchange_counts(int left, int right, const int32_t* dToLeft, const int32_t* dToRight, int32_t* dFromLeft, int32_t* dFromRight, int n,
+                                        hipStream_t stream)
+{
+    std::vector<int32_t> sl((size_t)n), sr((size_t)n), rl((size_t)n), rr((size_t)n);
+    const size_t bytes = sizeof(int32_t) * (size_t)n;
+    HIP_CHECK(hipMemcpyAsync(sl.data(), dToLeft, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(sr.data(), dToRight, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    int64_t got = 0;
+    if (sr_(ctx_, left, sl.data(), (int64_t)bytes, right, rr.data(), (int64_t)bytes, &got) != 0 || got != (int64_t)bytes)
+        throw std::runtime_error("slab count exchange callback failed (leftward)");
+    if (sr_(ctx_, right, sr.data(), (int64_t)bytes, left, rl.data(), (int64_t)bytes, &got) != 0 || got != (int64_t)bytes)
+        throw std::runtime_error("slab count exchange callback failed (rightward)");
+    HIP_CHECK(hipMemcpyAsync(dFromLeft, rl.data(), bytes, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(dFromRight, rr.data(), bytes, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
 void CallbackExchanger::allreduce_sum(double* host, int n, hipStream_t)
 {
     if (ar_(ctx_, host, n) != 0) throw std::runtime_error("slab allreduce callback failed");
@@ -113,16 +131,19 @@ __global__ void k_loopback_ranges(LoopArrays A, int nArr, int sLb, int sRb, int 
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     for (int k = 0; k < nArr; k++)
     {
+        // Between two sorts coordinates stay unwrapped and a ghost moves continuously with its source (the recorded image codes and cell shifts assume
+        // it): the copy is source + slab width + the multiple of L it had at the sort - recovered from the ghost's previous value, which is within an
+        // atom's step of where it belongs.  (Re-wrapping here made a ghost jump by L when its source drifted across the seam: its pairs were missed.)
         if (t < nToRight)
         {   // sent leftward -> arrives as "from the right"
             double v = A.a[k][sLb + t];
-            if (k == 0) { v += w; if (v < 0) v += L; else if (v >= L) v -= L; }
+            if (k == 0) { v += w; v += L * nearbyint((A.a[k][rRb + t] - v) / L); }
             A.a[k][rRb + t] = v;
         }
         if (t < nToLeft)
         {
             double v = A.a[k][sRb + t];
-            if (k == 0) { v -= w; if (v < 0) v += L; else if (v >= L) v -= L; }
+            if (k == 0) { v -= w; v += L * nearbyint((A.a[k][rLb + t] - v) / L); }
             A.a[k][rLb + t] = v;
         }
     }
@@ -132,9 +153,16 @@ void LoopbackExchanger::exchange_ranges(int, int, double* const* arrays, int nAr
                                         hipStream_t stream)
 {   // (sLn == rRn and sRn == rLn for a rank talking to itself)
     LoopArrays A{};
-    for (int k = 0; k < nArr && k < 4; k++) A.a[k] = arrays[k];
+    if (nArr > 4) throw std::runtime_error("slab loopback transport: at most 4 arrays per coordinate exchange");
+    for (int k = 0; k < nArr; k++) A.a[k] = arrays[k];
     const int nToRight = std::min(sLn, rRn), nToLeft = std::min(sRn, rLn), n = std::max(nToRight, nToLeft);
     if (n > 0) hipLaunchKernelGGL(k_loopback_ranges, dim3((n + 255) / 256), dim3(256), 0, stream, A, nArr, sLb, sRb, rLb, rRb, nToRight, nToLeft, w_, L_);
+}
+
+void LoopbackExchanger::exchange_counts(int, int, const int32_t* dToLeft, const int32_t* dToRight, int32_t* dFromLeft, int32_t* dFromRight, int n, hipStream_t stream)
+{   // what goes left comes back as the right neighbour's message and vice versa
+    HIP_CHECK(hipMemcpyAsync(dFromRight, dToLeft, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(dFromLeft, dToRight, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -242,6 +270,19 @@ void RcclExchanger::exchange_ranges(int left, int right, double* const* arrays, 
         check_nccl(a.Send(arrays[k] + sRb, (size_t)sRn, ncclDouble, right, c, stream), "ncclSend(right)");
         check_nccl(a.Recv(arrays[k] + rLb, (size_t)rLn, ncclDouble, left, c, stream), "ncclRecv(left)");
     }
+    check_nccl(a.GroupEnd(), "ncclGroupEnd");
+}
+
+void RcclExchanger::exchange_counts(int left, int right, const int32_t* dToLeft, const int32_t* dToRight, int32_t* dFromLeft, int32_t* dFromRight, int n,
+                                    hipStream_t stream)
+{   // fixed size on every rank, so this exchange cannot itself be mismatched; same pairing order as exchange()
+    RcclApi& a = rccl();
+    ncclComm_t c = (ncclComm_t)comm_;
+    check_nccl(a.GroupStart(), "ncclGroupStart");
+    check_nccl(a.Send(dToLeft, (size_t)n, ncclInt32, left, c, stream), "ncclSend(left)");
+    check_nccl(a.Recv(dFromRight, (size_t)n, ncclInt32, right, c, stream), "ncclRecv(right)");
+    check_nccl(a.Send(dToRight, (size_t)n, ncclInt32, right, c, stream), "ncclSend(right)");
+    check_nccl(a.Recv(dFromLeft, (size_t)n, ncclInt32, left, c, stream), "ncclRecv(left)");
     check_nccl(a.GroupEnd(), "ncclGroupEnd");
 }
 

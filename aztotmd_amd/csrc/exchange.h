@@ -27,6 +27,10 @@ public:
     // `right`; [rLb, rLb + rLn) arrive from `left`, [rRb, rRb + rRn) from `right` (the sender's counts equal the receiver's by construction)
     virtual void exchange_ranges(int left, int right, double* const* arrays, int nArr, int sLb, int sLn, int sRb, int sRn, int rLb, int rLn, int rRb,
                                  int rRn, hipStream_t stream) = 0;
+    // n 32-bit words to each neighbour and from each neighbour, between device buffers, ordered on `stream` (once per rebuild step: the ranks tell each
+    // other how many boundary atoms they will send on the plain steps, so that a disagreement is an error before a mismatched send / receive is posted)
+    virtual void exchange_counts(int left, int right, const int32_t* dToLeft, const int32_t* dToRight, int32_t* dFromLeft, int32_t* dFromRight, int n,
+                                 hipStream_t stream) = 0;
     // element-wise sum over ranks of n doubles held on the HOST (statistics; not on the per-step path)
     virtual void allreduce_sum(double* host, int n, hipStream_t stream) = 0;
     // element-wise sum over ranks of n doubles held on the DEVICE, ordered on `stream` (Ewald structure factors: a real
@@ -44,6 +48,8 @@ public:
     void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
                   hipStream_t stream) override;
     void exchange_ranges(int left, int right, double* const* arrays, int nArr, int sLb, int sLn, int sRb, int sRn, int rLb, int rLn, int rRb, int rRn,
+                         hipStream_t stream) override;
+    void exchange_counts(int left, int right, const int32_t* dToLeft, const int32_t* dToRight, int32_t* dFromLeft, int32_t* dFromRight, int n,
                          hipStream_t stream) override;
     void allreduce_sum(double* host, int n, hipStream_t stream) override;
     void allreduce_device(double* dev, int n, hipStream_t stream) override;
@@ -68,6 +74,8 @@ public:
                   hipStream_t stream) override;
     void exchange_ranges(int left, int right, double* const* arrays, int nArr, int sLb, int sLn, int sRb, int sRn, int rLb, int rLn, int rRb, int rRn,
                          hipStream_t stream) override;
+    void exchange_counts(int left, int right, const int32_t* dToLeft, const int32_t* dToRight, int32_t* dFromLeft, int32_t* dFromRight, int n,
+                         hipStream_t stream) override;
     void allreduce_sum(double*, int, hipStream_t) override {}
     void allreduce_device(double*, int, hipStream_t) override {}
     bool device_side() const override { return true; }
@@ -85,6 +93,8 @@ public:
     void exchange(int left, int right, const void* dSendLeft, const void* dSendRight, void* dFromLeft, void* dFromRight, size_t bytes,
                   hipStream_t stream) override;
     void exchange_ranges(int left, int right, double* const* arrays, int nArr, int sLb, int sLn, int sRb, int sRn, int rLb, int rLn, int rRb, int rRn,
+                         hipStream_t stream) override;
+    void exchange_counts(int left, int right, const int32_t* dToLeft, const int32_t* dToRight, int32_t* dFromLeft, int32_t* dFromRight, int n,
                          hipStream_t stream) override;
     void allreduce_sum(double* host, int n, hipStream_t stream) override;
     void allreduce_device(double* dev, int n, hipStream_t stream) override;

@@ -745,6 +745,11 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
             {   // what the host needs to address the boundary layers in the plain steps' coordinate exchange: one small copy instead of three
                 haloInfo[0] = cellStart[2 * P.hw[0] * plane]; haloInfo[1] = cellStart[(P.ncxLocal - 2 * P.hw[0]) * plane];
                 haloInfo[2] = ob; haloInfo[3] = oe; haloInfo[4] = cnt->nTotal;
+                // what this rank will send on every plain step until the next sort: to the left neighbour its first 2 hw owned layers, to the right one its
+                // last 2 hw - each neighbour must hold exactly that many ghosts on that side (checked before the first plain step: Engine::take_halo_info)
+                // (each message also carries the ghost count of that side, so that both ranks of a boundary see both numbers and arrive at the same verdict)
+                haloInfo[5] = haloInfo[0] - ob; haloInfo[6] = ob;                          // to the left neighbour: {what I send leftward, my left ghosts}
+                haloInfo[10] = oe - haloInfo[1]; haloInfo[11] = cnt->nTotal - oe;          // to the right neighbour: {what I send rightward, my right ghosts}
             }
         }
         else { cntOut->ownedBegin = 0; cntOut->ownedEnd = cnt->nTotal; }

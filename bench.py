@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="C4", help="C4 (1 000 188 Ar LJ, default), C3 (+Fennell Coulomb), C2 (40 000 Ar LJ), M4 (1 029 000 atoms in bonded triatomics)")
+    ap.add_argument("--workload", default="C4", help="C4 (1 000 188 Ar LJ, default), C4T (the same at 85 K), C4X, C3 / C3T (+Fennell Coulomb), C2 / C2T (40 000 Ar LJ), M4, S4, S40, B3, E2")
     ap.add_argument("--pair-variant", type=int, default=0)
     ap.add_argument("--cell-size", type=float, default=0.0)
     ap.add_argument("--sort-every", type=int, default=0, help="cell-list rebuild schedule: 0 adaptive lazy re-sort (default), 1 every step (the reference's), n at most every n-th step")
@@ -103,47 +103,58 @@ def _cpu_model():
     return "unknown"
 
 
+# kernels that run only on a step that rebuilds the cell list (everything else runs on every step)
+REBUILD_ONLY = ("integrate1_bin", "bin", "scan_cells", "place", "rank_gather", "build_lists", "exchange", "unpack_halo")
+WORKLOADS = {"C4": "1 000 188 Ar, LJ rc 8.5 A, FCC 63^3 a=5.735 jitter 0.15, dt 1 fs, NVE, init_vel zero (BASELINE config '1 000 000 Ar LJ', SURVEY C4)",
+             "C4T": "C4 thermalised: Maxwell velocities at 85 K (init_vel gaus), equilibrates to ~44 K kinetic + lattice potential",
+             "C4X": "C4's lattice in a box of exactly 42 x 8.5 A (no overhang of the cells over the cut-off)",
+             "C3": "1 000 188 atoms, LJ rc 8.5 A + Fennell/DSF Coulomb q=+-0.2 (SURVEY C3)",
+             "C3T": "C3 thermalised: Maxwell velocities at 85 K",
+             "C2": "40 000 Ar, LJ rc 8.5 A (SURVEY C2)", "C2T": "C2 thermalised: Maxwell velocities at 85 K",
+             "S4": "4 000 atoms, surk rc 6.0 + radii on 2.7 A cells, radiative thermostat 500 K (periodic analogue of case study 2)",
+             "S40": "40 000 atoms, surk rc 6.0 + radii on 2.7 A cells, radiative thermostat 500 K",
+             "M4": "1 029 000 atoms in 343 000 bonded triatomics (5 bond potentials, hcos angles), LJ + Fennell",
+             "B3": "1 000 188 ions, Born-Mayer-Huggins + Fennell (heats up from a lattice)",
+             "E2": "40 000 ions, LJ + full Ewald sum (4 231 k-vectors)"}
+
+
 def main():
     a = parse()
-    # the contract is ONE JSON line on stdout: keep library chatter (gloo, RCCL, HIP runtime) away from it
+    # the contract is ONE JSON line on stdout: keep library chatter (RCCL, HIP runtime) away from it
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
-    import numpy as np
-    import torch
-    from aztotmd_amd import api, inputs
+    import numpy as np  # noqa: F401
+    # NO torch in this process: the ranks bring up RCCL inside libaztot (system ROCm runtime), and torch's wheel would put its own HIP / HSA copies in
+    # front of it.  The launcher (python -m torch.distributed.run) only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; the control plane
+    # (RCCL id, barriers, a few scalars) is aztotmd_amd.ctl over plain TCP.
+    from aztotmd_amd import api, ctl, inputs
 
-    dist = None
+    cp = ctl.Control()
+    rank, world = cp.rank, cp.world
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only; data path = RCCL in libaztot
-    ndev = torch.cuda.device_count()
+        a.gpus = world
+    ndev = api.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     oversubscribed = world > ndev          # rehearsal on a box with fewer GPUs than ranks: ranks share devices, RCCL cannot be used
-    local_rank = local_rank % ndev
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % ndev
 
     case = inputs.config(a.workload)
     n_atoms = len(case["types"])
     model = api.Model.from_case(case)
     slab = None
     if world > 1:
-        idb = [api.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(idb, src=0)
-        slab = {"rank": rank, "nranks": world, "rccl_id": idb[0]}
+        idb = cp.broadcast(api.rccl_unique_id() if rank == 0 else None)
+        slab = {"rank": rank, "nranks": world, "rccl_id": idb}
     if a.emulate_ranks > 1 and world == 1:
         slab = {"rank": a.emulate_ranks // 2, "nranks": a.emulate_ranks, "loopback": True}
     transport = "single GPU"
+    kw = dict(device=dev, initial_forces=1, pair_variant=a.pair_variant, cell_size=a.cell_size, debug=a.debug, sort_every=a.sort_every, split=a.split, skin=a.skin)
+    err = ""
     try:
-        eng = api.Engine(model, device=local_rank, initial_forces=1, pair_variant=a.pair_variant, cell_size=a.cell_size,
-                         use_graph=0 if a.no_graph else 1, profile=0, slab=slab, debug=a.debug, sort_every=a.sort_every, split=a.split, skin=a.skin)
+        eng = api.Engine(model, use_graph=0 if a.no_graph else 1, profile=0, slab=slab, **kw)
         if world > 1:
             transport = "RCCL send/recv over xGMI"
         if a.emulate_ranks > 1:
@@ -153,52 +164,43 @@ def main():
         if world == 1:
             raise
         ok, err = 0, str(ex)
-    if world > 1:
-        t = torch.tensor([ok])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) == 0:
-            if ok:
-                eng.close()                  # ranks whose engine came up: release it before anything else is built
-            if not oversubscribed:
-                # one GPU per rank and RCCL does not come up: that is a failed run, not a slower one - a scaling record must
-                # never report "ok" with the halo travelling through the host
-                if rank == 0:
-                    sys.stderr.write("bench.py: RCCL initialisation failed with one GPU per rank: %s\n" % (err if not ok else "on another rank"))
-                dist.barrier()
-                dist.destroy_process_group()
-                raise SystemExit(3)
-            # rehearsal on a box with fewer GPUs than ranks (RCCL cannot put two ranks on one device): host-staged transport over
-            # gloo, clearly labelled, never a result
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from slab_worker import make_transport
-            sr, ar = make_transport()
-            slab = {"rank": rank, "nranks": world, "sendrecv": sr, "allreduce": ar}
-            eng = api.Engine(model, device=local_rank, initial_forces=1, pair_variant=a.pair_variant, cell_size=a.cell_size,
-                             use_graph=0, profile=0, slab=slab, debug=a.debug)
-            transport = "REHEARSAL: host-staged over gloo, ranks share GPUs - not a result"
+    if world > 1 and cp.all_min(ok) == 0:
+        if ok:
+            eng.close()                  # ranks whose engine came up: release it before anything else is built
+        if not oversubscribed:
+            # one GPU per rank and RCCL does not come up: that is a failed run, not a slower one - a scaling record must
+            # never report "ok" with the halo travelling through the host
+            sys.stderr.write("bench.py rank %d: RCCL initialisation failed with one GPU per rank: %s\n" % (rank, err if not ok else "on another rank"))
+            cp.barrier()
+            cp.close()
+            raise SystemExit(3)
+        # rehearsal on a box with fewer GPUs than ranks (RCCL cannot put two ranks on one device): host-staged transport relayed by the
+        # control plane, clearly labelled, never a result
+        slab = {"rank": rank, "nranks": world, "sendrecv": lambda sp, data, rp, rcap: cp.sendrecv(sp, bytes(data), rp),
+                "allreduce": lambda arr: np.asarray(cp.all_sum(arr.tolist()))}
+        eng = api.Engine(model, use_graph=0, profile=0, slab=slab, **kw)
+        transport = "REHEARSAL: host-staged over TCP, ranks share GPUs - not a result"
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+        cp.barrier()
+        api.device_synchronize(dev)
 
     rccl_ranks = eng.comm_ranks()            # ncclCommCount of the communicator the halo travels on (0: no RCCL)
     if world > 1 and not oversubscribed and rccl_ranks != world:
         raise SystemExit("bench.py: %d ranks but the RCCL communicator has %d" % (world, rccl_ranks))
 
-    # ---- timed region: EXACTLY a.steps steps, no per-kernel instrumentation (the step is replayed as a hipGraph on 1 GPU)
+    # ---- timed region: EXACTLY a.steps steps, no per-kernel instrumentation (the step is replayed as a hipGraph where that pays)
     eng.step(a.warmup)
+    st0 = eng.stats()
     barrier()
     t0 = time.perf_counter()
     eng.step(a.steps)             # returns after the engine's stream has drained
     barrier()
     wall = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    if world > 1:
+        wall = cp.all_max(wall)
     st = eng.stats()
+    rebuilds_in_window = st["rebuilds"] - st0["rebuilds"]
     # ---- second pass over the same number of steps with HIP events around every kernel (on the engine's own stream):
     #      source of the per-kernel durations / the roofline figure; its wall time is reported separately
     ktimes, wall_events = {}, None
@@ -207,44 +209,60 @@ def main():
         eng.reset_kernel_times()
         barrier()
         t0 = time.perf_counter()
-        eng.step(a.steps)
+        eng.step(max(a.steps, 2 * int(st["sort_interval"]) + 2))      # (at least two sort intervals, so that every kernel of the cycle is seen)
         barrier()
-        wall_events = time.perf_counter() - t0
+        wall_events = (time.perf_counter() - t0) / max(a.steps, 2 * int(st["sort_interval"]) + 2) * a.steps
         ktimes = eng.kernel_times()
         eng.set_profile(0)
     profile = 0 if a.no_profile else 1
-    if dist is not None and profile:
+    if world > 1 and profile:
         # slowest rank per kernel
         names = sorted(ktimes)
-        t = torch.tensor([ktimes[k]["ms"] / max(ktimes[k]["calls"], 1) for k in names], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        for k, v in zip(names, t.tolist()):
+        mine = [ktimes[k]["ms"] / max(ktimes[k]["calls"], 1) for k in names]
+        for k, v in zip(names, [max(col) for col in zip(*cp.all_gather(mine))]):
             ktimes[k]["avg_ms_max_over_ranks"] = v
 
     if rank == 0:
         dt_ps = case["dt"]
-        ms_per_step = wall / a.steps * 1e3
-        nsday = a.steps * dt_ps * 1e-3 / wall * 86400.0
+        K = max(int(st["sort_interval"]), 1)
         out = {
-            "metric": "ns_per_day", "value": nsday, "unit": "ns/day", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "metric": "ns_per_day", "value": None, "unit": "ns/day", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": {"C4": "1 000 188 Ar, LJ rc 8.5 A, FCC 63^3 a=5.735 jitter 0.15, dt 1 fs, NVE (BASELINE config '1 000 000 Ar LJ', SURVEY C4)",
-                                    "C3": "1 000 188 atoms, LJ rc 8.5 A + Fennell/DSF Coulomb q=+-0.2 (SURVEY C3)",
-                                    "C2": "40 000 Ar, LJ rc 8.5 A (SURVEY C2)",
-                                    "S4": "4 000 atoms, surk rc 6.0 + radii on 2.7 A cells, radiative thermostat 500 K (periodic analogue of case study 2)",
-                                    "S40": "40 000 atoms, surk rc 6.0 + radii on 2.7 A cells, radiative thermostat 500 K"}.get(a.workload, a.workload),
+            "config": {"workload": WORKLOADS.get(a.workload, a.workload),
                        "n_atoms": n_atoms, "n_cells": st["n_cells"], "decomposition": "single GPU" if world == 1 else "%d slabs along x" % world, "transport": transport, "rccl_ranks": rccl_ranks, "ranks_share_gpus": oversubscribed,
-                       "pair_variant": a.pair_variant, "sort_interval": st.get("sort_interval"), "sort_violations": st.get("sort_violations"),
+                       "pair_variant": a.pair_variant, "sort_interval": st.get("sort_interval"), "sort_violations": st.get("sort_violations"), "skin_A": st.get("skin"),
+                       "temperature_K": st.get("temperature"),
                        "pair_lists": st.get("pair_lists"), "cells_without_list": st.get("cells_without_list"),
-                       "kernel_timing": "second pass of the same %d steps with HIP events on the engine stream" % a.steps if profile else "off"},
-            "matom_steps_per_s": n_atoms * a.steps / wall / 1e6,
-            "ms_per_step_with_events": (wall_events / a.steps * 1e3) if wall_events else None,
+                       "kernel_timing": "second pass with HIP events on the engine stream" if profile else "off"},
             "energy": {"engTot": st["engTot"], "engVdW": st["engVdW"], "engKin": st["engKin"], "pairs_dropped": st["pairs_dropped"]},
         }
+        kern = {}
         if ktimes:
             kern = {k: {"avg_us": 1e3 * v.get("avg_ms_max_over_ranks", v["ms"] / max(v["calls"], 1)), "calls": v["calls"]} for k, v in ktimes.items()}
             out["kernels"] = kern
+        # ---- what the timed window held.  The cell list is rebuilt every K-th step only (the reference: every step, main.cu:300-326); a window of fewer
+        # steps than K may hold no rebuild at all.  `value` never profits from that: when the window holds fewer rebuilds than its share steps / K, the
+        # missing ones are charged at the measured cost of a rebuild step (event-timed kernels that run on rebuild steps only, minus the plain
+        # integrate kernel they replace).
+        rebuild_us = None
+        if kern:
+            rebuild_us = sum(kern[k]["avg_us"] for k in REBUILD_ONLY if k in kern and kern[k]["calls"] > 0)
+            if "integrate1" in kern and kern["integrate1"]["calls"] > 0 and rebuild_us > 0:
+                rebuild_us -= kern["integrate1"]["avg_us"]
+        share = a.steps / K
+        missing = max(0.0, share - rebuilds_in_window) if K > 1 else 0.0
+        wall_charged = wall + (missing * rebuild_us * 1e-6 if rebuild_us else 0.0)
+        out["ms_per_step"] = wall_charged / a.steps * 1e3
+        out["value"] = a.steps * dt_ps * 1e-3 / wall_charged * 86400.0
+        out["matom_steps_per_s"] = n_atoms * a.steps / wall_charged / 1e6
+        out["timed_window"] = {"ms_per_step_as_measured": wall / a.steps * 1e3, "rebuilds_in_timed_region": rebuilds_in_window, "fair_share_of_rebuilds": share,
+                               "rebuild_step_extra_us": rebuild_us, "amortised_rebuild_us_per_step": (rebuild_us / K) if rebuild_us else None,
+                               "charged_for_missing_rebuilds_ms": (wall_charged - wall) * 1e3,
+                               "pair_energies": "booked on the last step of the call only (the only one whose statistics the caller can see); "
+                                                "energies_on_every_step_ms_per_step is the same run with options.energies_every_step = 1"}
+        out["ms_per_step_with_events"] = (wall_events / a.steps * 1e3) if wall_events else None
+        if kern:
             # the pair kernel that carries the run: largest total time (plain steps of the lazy re-sort: pair_list; steps that rebuild the cells: pair_tile)
             pair_name = max((k for k in kern if k.startswith("pair")), key=lambda k: kern[k]["avg_us"] * kern[k]["calls"], default=None)
             if pair_name:
@@ -273,19 +291,32 @@ def main():
                                    "fp64_peak_tflops": FP64_VECTOR_PEAK / 1e12,
                                    "counters_from": rec.get("round"),
                                    "note": "frac counts the COMPULSORY bytes (52 B/atom + 8 B/cell); traffic is what the kernel really moves - pair_list streams its "
-                                           "candidate and pair lists (about 3.3 KB per cell, recorded when the cells were rebuilt) once per step, which is what replaces "
-                                           "staging, filtering and mask handling; fp64_flop_per_launch = (2 FMA + ADD + MUL + TRANS) x 64 + 512 MFMA_MOPS from the "
+                                           "candidate and pair lists (recorded when the cells were rebuilt) once per step, which is what replaces "
+                                           "staging, filtering and mask handling; fp64_flop_per_launch = (2 FMA + ADD + MUL + TRANS) x 64 from the "
                                            "SQ_INSTS_VALU_*_F64 counters in profiles/"}
             # the streaming kernels: algorithmic bytes / launch time / HBM peak
             n_local = n_atoms / world
             stream = {}
             for k, b in STREAM_BYTES_PER_ATOM.items():
                 if k in kern and kern[k]["calls"] > 0:
-                    bb = b + (32.0 if (k == "rank_gather" and case.get("tstat_type", 0) == 2) else 0.0)
+                    bb = b + (32.0 if (k == "rank_gather" and case.get("tstat_type", 0) == 2) else 0.0) + (16.0 if (k == "rank_gather" and st.get("pair_lists")) else 0.0)
                     t_k = kern[k]["avg_us"] * 1e-6
                     stream[k] = {"bytes_per_atom": bb, "avg_us": kern[k]["avg_us"], "gbps": bb * n_local / t_k / 1e9, "hbm_frac": bb * n_local / t_k / HBM_PEAK}
             out["streaming"] = stream
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.emulate_ranks <= 1:
+            # the same timed region with pair energies booked on every step (options.energies_every_step): what a caller who asks for statistics after every
+            # single step would see
+            try:
+                e2 = api.Engine(model, use_graph=0 if a.no_graph else 1, profile=0, energies_every_step=1, **kw)
+                e2.step(a.warmup)
+                api.device_synchronize(dev)
+                t0 = time.perf_counter()
+                e2.step(a.steps)
+                api.device_synchronize(dev)
+                out["timed_window"]["energies_on_every_step_ms_per_step"] = (time.perf_counter() - t0) / a.steps * 1e3
+                e2.close()
+            except Exception as ex:   # noqa: BLE001
+                out["timed_window"]["energies_on_every_step_ms_per_step"] = "failed: %r" % (ex,)
             steps_cpu = a.cpu_steps or max(2, int(round(5.0e6 / n_atoms * 1.0)))   # ~3 us per atom-step -> about 15 s
             steps_cpu = min(steps_cpu, 200)
             try:
@@ -294,7 +325,7 @@ def main():
                 if ref_e and ref_e.get("engTot") is not None:
                     # same inputs, same number of steps, same start (F = 0 as the reference sample): the HIP path's energies next to
                     # the CPU reference's, in this very run (force-level parity is the test suite's job)
-                    chk = api.Engine(model, device=local_rank, initial_forces=0, pair_variant=a.pair_variant, cell_size=a.cell_size)
+                    chk = api.Engine(model, device=dev, initial_forces=0, pair_variant=a.pair_variant, cell_size=a.cell_size, skin=a.skin)
                     chk.step(steps_cpu)
                     cs = chk.stats()
                     chk.close()
@@ -309,9 +340,9 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     eng.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if world > 1:
+        cp.barrier()
+    cp.close()
 
 
 if __name__ == "__main__":

@@ -171,7 +171,9 @@ typedef struct
     int64_t sort_interval;       /* steps between two rebuilds of the cell list that the next aztot_step call will use (1: every step) */
     int64_t sort_violations;     /* calls so far in which an atom left its cell's slack before the scheduled rebuild (handled exactly, by a wider stencil) */
     int64_t pair_lists;          /* 1: the steps between two rebuilds walk per-atom pair lists recorded at the rebuild (k_pair_list) ; 0: they stage every cell */
-    int64_t cells_without_list;  /* cells whose stencil did not fit one tile / with more partners than a list holds at the last rebuild: staged in full */
+    int64_t cells_without_list;  /* cells that did not fit the lists at the last rebuild (more than 64 atoms, tile or list full): staged in full every step */
+    int64_t rebuilds;            /* steps so far that rebuilt the cell list (clear_clist .. sort_atoms of main.cu:300-326; the reference: every step) */
+    double skin;                 /* the Verlet skin in force, Angstrom: pair lists reach cut-off + skin, an atom may move skin / 2 between two rebuilds (0: none) */
 } aztot_stats;
 
 /* host copy of the per-atom state, fp64 SoA, in ORIGINAL atom order (id order); any pointer may be NULL */
@@ -199,6 +201,8 @@ void aztot_free_md(aztot_model *m);
 /* ---- device: replaces init_cudaMD / md_to_host / free_device_md (cuInit.h:4,6,7) --------------------- */
 /* number of HIP devices this process can use (0: none, never negative); the reference takes device 0 unasked (cuInit.cu:688) */
 int aztot_device_count(void);
+/* blocks until device `device` has finished all work queued by this process (hipDeviceSynchronize): what a launcher brackets a timed region with */
+int aztot_device_synchronize(int device);
 void aztot_default_options(aztot_options *opt);
 int aztot_init_device(const aztot_model *m, const aztot_options *opt, aztot_md **out);
 void aztot_free_device(aztot_md *md);
@@ -216,6 +220,19 @@ int aztot_get_stats(aztot_md *md, aztot_stats *out);
 int aztot_species_crossings(aztot_md *md, int64_t *out, int cap);
 int aztot_md_to_host(aztot_md *md, aztot_state *out);
 int aztot_set_state(aztot_md *md, const aztot_state *in);
+/* Restart support (checkpoint row): the scalars of the device state that aztot_md_to_host / aztot_set_state do not carry.  A run restarted with
+   aztot_set_state (x, v, f, U, radius of the checkpoint) + aztot_set_clock continues exactly: the step number drives the equilibration schedule
+   (sys_init.cpp:700-712, nequil / eqfreq) and keys the thermostat's counter-based random numbers; the Nose-Hoover pair (temperature.h:24-25) and the
+   kinetic energy the thermostats saw last (sim->engKin, integrators.cpp:305) are the thermostat's memory.  Wall-momentum and crossing counters restart
+   from zero (they are running sums for the statistics, never fed back into the dynamics). */
+typedef struct
+{
+    int64_t step;                /* completed steps (aztot_stats.step) */
+    double nose_chit, nose_conint;
+    double eng_kin;              /* kinetic energy after the last completed step, eV */
+} aztot_clock;
+int aztot_get_clock(aztot_md *md, aztot_clock *out);
+int aztot_set_clock(aztot_md *md, const aztot_clock *in);
 /* the cell list as the device holds it after the last sort: cudaMD::firstAtomInCell / cellIndexes (cuStruct.h:219-222;
    calc_firstAtomInCell cuSort.cu:130-143, sort_atoms cuSort.cu:145-197).  dims[3] = cells per axis of this rank's window;
    cell_start[c] = first slot of cell c = (ix * ny + iy) * nz + iz (n_cells + 1 entries, the last one = resident atoms);

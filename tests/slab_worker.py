@@ -1,42 +1,45 @@
-"""Worker for the slab-decomposition tests: run under torch.distributed.run with N ranks (gloo control plane).
+"""Worker for the slab-decomposition tests: run under torch.distributed.run with N ranks.
 
 Every rank owns one x-slab of the SAME system and drives the real HIP engine; halos/migrants travel either
 through RCCL (one GPU per rank) or - when several ranks have to share one GPU - through the host-staged callback
-transport over gloo.  Rank 0 gathers the per-atom state and compares it with a single-rank engine and the oracle.
+transport, relayed by the control plane.  Rank 0 gathers the per-atom state and compares it with a single-rank engine.
+torch is NOT imported here (its wheel's HIP / HSA copies would sit in front of the system runtime RCCL needs): the control
+plane is aztotmd_amd.ctl (plain TCP; rank, world size and the master address come from the launcher's environment).
+transport 'callback_corrupt': rank 0 lies by one atom in the count message of the rebuild steps - every rank of that
+boundary must then report AZTOT_ERR_COMM before any plain step's exchange is posted.
 """
 import json
 import os
+import struct
 import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from aztotmd_amd import api, inputs  # noqa: E402
+from aztotmd_amd import api, ctl, inputs  # noqa: E402
 
 
-def make_transport():
-    state = {"n": 0}
-
+def make_transport(cp, corrupt=False):
     def sendrecv(send_peer, data, recv_peer, rcap):
-        tag = state["n"] & 1
-        state["n"] += 1
-        ts = torch.frombuffer(bytearray(data), dtype=torch.uint8)
-        tr = torch.empty(rcap, dtype=torch.uint8)
-        if send_peer == dist.get_rank():          # single-rank ring: message to self
-            return bytes(data)
-        req = dist.isend(ts, dst=send_peer, tag=tag)
-        dist.recv(tr, src=recv_peer, tag=tag)
-        req.wait()
-        return tr.numpy().tobytes()
+        data = bytes(data)
+        if corrupt and cp.rank == 0 and len(data) == 8:
+            # the count message of a rebuild step ({atoms I will send you per plain step, ghosts I hold on your side}): claim one atom more
+            n, g = struct.unpack("<ii", data)
+            data = struct.pack("<ii", n + 1, g)
+        if send_peer == cp.rank and recv_peer == cp.rank:          # single-rank ring: message to self
+            return data
+        got = cp.sendrecv(send_peer, data, recv_peer)
+        if corrupt and cp.rank == 0 and len(got) == 8:
+            # ... and see the neighbour's numbers off by one too: a real disagreement is visible from both sides of the boundary (both ranks evaluate
+            # the same two equalities), so both must fail
+            n, g = struct.unpack("<ii", got)
+            got = struct.pack("<ii", n, g + 1)
+        return got
 
     def allreduce(a):
-        t = torch.from_numpy(np.ascontiguousarray(a))
-        dist.all_reduce(t)
-        return t.numpy()
+        return np.asarray(cp.all_sum(np.asarray(a, dtype=np.float64).tolist()))
 
     return sendrecv, allreduce
 
@@ -44,9 +47,9 @@ def make_transport():
 def main():
     name, nsteps, transport = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     extra = json.loads(sys.argv[4]) if len(sys.argv) > 4 else {}
-    dist.init_process_group(backend="gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
-    ngpu = torch.cuda.device_count()
+    cp = ctl.Control()
+    rank, world = cp.rank, cp.world
+    ngpu = api.device_count()
     dev = rank % max(ngpu, 1)
     if name == "thermo":
         case = inputs.lj_case((12, 5, 5), a=5.26, seed=11, rc=6.5, cell_list=6.5, T=298.0, tstat="radi", vel_T=150.0,
@@ -75,14 +78,27 @@ def main():
         case = inputs.lj_case((16, 6, 6), a=5.26, seed=5, vel_T=120.0)
     model = api.Model.from_case(case)
     if transport == "rccl":
-        idb = [api.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(idb, src=0)
-        slab = {"rank": rank, "nranks": world, "rccl_id": idb[0]}
+        idb = cp.broadcast(api.rccl_unique_id() if rank == 0 else None)
+        slab = {"rank": rank, "nranks": world, "rccl_id": idb}
     else:
-        sr, ar = make_transport()
+        sr, ar = make_transport(cp, corrupt=(transport == "callback_corrupt"))
         slab = {"rank": rank, "nranks": world, "sendrecv": sr, "allreduce": ar}
     eng = api.Engine(model, device=dev, slab=slab, **extra)
     first = max(1, nsteps // 3)
+    if transport == "callback_corrupt":
+        # every rank must come back with AZTOT_ERR_COMM (-5) instead of hanging or shifting coordinates onto the wrong atoms
+        code, msg = 0, ""
+        try:
+            eng.step(first)
+            eng.step(nsteps - first)
+        except api.AztotError as ex:
+            code, msg = ex.code, str(ex)
+        codes = cp.all_gather(code)
+        if rank == 0:
+            print("SLAB_RESULT " + json.dumps({"world": world, "transport": transport, "codes": codes, "message": msg}))
+        cp.barrier()
+        cp.close()
+        return
     eng.step(first)                      # two calls: the second one runs on the sort interval the first one measured
     eng.step(nsteps - first)
     st = eng.stats()
@@ -90,15 +106,10 @@ def main():
     s = eng.state()
     keys = ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz", "U", "radius")
     owned = ~np.isnan(s["x"])
-    counts = torch.tensor([int(owned.sum())])
-    dist.all_reduce(counts)
-    merged = {}
-    for k in keys:
-        t = torch.from_numpy(np.nan_to_num(s[k], nan=0.0))
-        dist.all_reduce(t)
-        merged[k] = t.numpy()
-    cover = torch.from_numpy(owned.astype(np.int32))
-    dist.all_reduce(cover)
+    parts = cp.all_gather((owned, {k: np.nan_to_num(s[k], nan=0.0) for k in keys}))
+    owned_total = int(sum(int(o.sum()) for o, _ in parts))
+    merged = {k: sum(d[k] for _, d in parts) for k in keys}
+    cover = sum(o.astype(np.int32) for o, _ in parts)
     out = None
     if rank == 0:
         ref = api.Engine(api.Model.from_case(case), device=dev, **extra)
@@ -107,16 +118,16 @@ def main():
         rs, rst = ref.state(), ref.stats()
         from util import rel_err
         errs = {k: rel_err(merged[k], rs[k]) for k in keys if np.abs(rs[k]).max() > 0}
-        out = {"world": world, "transport": transport, "rccl_ranks": eng.comm_ranks(), "n_atoms": len(case["types"]), "sort_interval": st["sort_interval"], "owned_total": int(counts.item()),
-               "every_atom_owned_once": bool((cover.numpy() == 1).all()), "max_rel_err_vs_single": max(errs.values()), "errs": errs,
+        out = {"world": world, "transport": transport, "rccl_ranks": eng.comm_ranks(), "n_atoms": len(case["types"]), "sort_interval": st["sort_interval"], "owned_total": owned_total,
+               "every_atom_owned_once": bool((cover == 1).all()), "max_rel_err_vs_single": max(errs.values()), "errs": errs,
                "energy_rel": {k: abs(st[k] - rst[k]) / (abs(rst[k]) + 1e-300) for k in ("engTot", "engVdW", "engKin", "engCoul", "engTemp", "engBond", "engAngle", "engCoulRec", "engCoulConst") if abs(rst[k]) > 0},
                "cross": [st["negCross"], st["posCross"], rst["negCross"], rst["posCross"]],
                "species_cross_equal": bool(np.array_equal(spec_cross, ref.species_crossings())),
                "mom_rel": rel_err(st["posMom"] + st["negMom"], rst["posMom"] + rst["negMom"]) if any(rst["posMom"] + rst["negMom"]) else 0.0}
         print("SLAB_RESULT " + json.dumps(out))
     eng.close()
-    dist.barrier()
-    dist.destroy_process_group()
+    cp.barrier()
+    cp.close()
 
 
 if __name__ == "__main__":

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     # sizes computed from the C declarations (natural alignment, x86-64)
     assert ctypes.sizeof(api._Species) == 56 and ctypes.sizeof(api._Vdw) == 64
     assert ctypes.sizeof(api._Options) == 96 and ctypes.sizeof(api._State) == 104
-    assert ctypes.sizeof(api._Stats) == 280
+    assert ctypes.sizeof(api._Stats) == 296
     assert ctypes.sizeof(api._BondType) == 56 and ctypes.sizeof(api._AngleType) == 24 and ctypes.sizeof(api._Bonded) == 88
 
 

@@ -43,6 +43,19 @@ def test_cli_reproduces_oracle(tmp_path):
         assert int(row[1]) == int(st["iStep"])
         for col, key in ((2, "engTot"), (3, "engKin"), (4, "engVdW"), (7, "engTemp")):
             assert abs(float(row[col]) - st[key]) <= 2e-6 + 1e-9 * abs(st[key]), (row[1], key, row[col], st[key])
+    # the `press` column (start_stat cuStat.cu:308-330; main.cpp:143-163): wall-momentum pressure over the window since the previous line, from the
+    # momenta the same line prints (columns momPx momNx momPy momNy momPz momNz, %f)
+    ipx = rows[0].index("momPx")
+    assert rows[0][ipx + 6] == "press" and rows[1][ipx + 6] == "press, atm"
+    L = case["box"]
+    rev_area = [1.0 / (L[1] * L[2])] * 2 + [1.0 / (L[0] * L[2])] * 2 + [1.0 / (L[0] * L[1])] * 2
+    prev = [0.0] * 6
+    for row in rows[2:]:
+        mom = [float(v) for v in row[ipx:ipx + 6]]
+        want = sum(2.0 * 1.58e6 * ra * (m1 - m0) / (20 * case["dt"]) for ra, m1, m0 in zip(rev_area, mom, prev)) / 6.0
+        prev = mom
+        tol = 2.0 * 1.58e6 * max(rev_area) * 1e-6 / (20 * case["dt"]) * 6 + 1e-6 * abs(want)          # the momenta are printed with six decimals
+        assert abs(float(row[ipx + 6]) - want) <= tol, (row[1], row[ipx + 6], want)
     s = o.state()
     rev = open(os.path.join(d, "revcon.xyz")).read().splitlines()
     assert int(rev[0]) == 4000 and rev[1].split()[0] == "1"

@@ -262,3 +262,32 @@ def test_case_study_2_through_the_hip_path(tmp_path):
     e1.step(12); e2.step(12)
     for k in ("x", "vx", "fx", "U", "radius"):
         assert np.array_equal(e1.state()[k], e2.state()[k]), k
+
+
+@pytest.mark.parametrize("name", ["C4T", "C3T"])
+def test_thermalised_liquid_at_full_size(name):
+    """BASELINE configs 4 and 3 with Maxwell velocities at argon's 85 K (`init_vel gaus`; the reference rebuilds its cell list every step, main.cu:300-326, so
+    its cost does not depend on temperature - the lazy schedule's does): the DEFAULT engine (automatic skin, pair lists, adaptive interval - capped at 4 steps
+    here so that 18 steps of the serial reference span the measuring phase and two and a half sort intervals) against the reference's serial code at all
+    1 000 188 atoms, per-atom x / v / f to 1e-9 (north star), energies to 1e-11."""
+    case = inputs.config(name)
+    ref, eref, who = cpu_steps(case, 18)
+    e = api.Engine(api.Model.from_case(case), initial_forces=0, sort_every=4)
+    e.step(8)                   # the engine measures the atoms' speed (interval 1)
+    r0 = e.stats()["rebuilds"]
+    e.step(10)                  # interval 4: rebuilds at two or three of these steps, lists walked on the others
+    s, st = e.state(), e.stats()
+    assert st["sort_interval"] == 4 and st["pair_lists"] == 1 and st["sort_violations"] == 0 and st["cells_without_list"] == 0, st
+    assert 2 <= st["rebuilds"] - r0 <= 3 and 0.25 < st["skin"] < 0.5 and st["n_cells"] < 42 ** 3, st
+    assert 30.0 < st["temperature"] < 90.0, st["temperature"]
+    for k in XVF:
+        assert rel_err(s[k], ref[k]) < 1e-9, (name, who, k, rel_err(s[k], ref[k]))
+    for k, v in eref.items():
+        assert abs(st[k] - v) <= 1e-11 * abs(v) + 1e-12, (name, who, k, st[k], v)
+    assert st["pairs_dropped"] == 0
+    # and the run goes on at the interval the speeds allow: a thermalised liquid keeps its lists for ten steps and more
+    f = api.Engine(api.Model.from_case(case))
+    for n in (10, 40, 40):
+        f.step(n)
+    stf = f.stats()
+    assert stf["sort_interval"] >= 10 and stf["sort_violations"] == 0 and stf["pair_lists"] == 1 and stf["cells_without_list"] == 0, stf

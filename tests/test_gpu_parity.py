@@ -924,3 +924,148 @@ def test_c2_40k_energy_conservation_and_newton3():
     st = e.stats()
     assert abs(st["engTot"] - e0) < 2e-4 * abs(e0)      # NVE drift over 200 fs from a cold jittered lattice (unshifted cut-off)
     assert st["pairs_dropped"] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# round 3: explicit Verlet skin, lists for any cell population, restart, pressure
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_box_that_is_a_whole_number_of_cutoffs_still_gets_a_skin():
+    """L = 6 x rc exactly: the reference's split_cells (cuCellList.cu:9-34) makes cells of exactly rc, which used to leave the lazy re-sort no slack at all
+    (interval 1, no lists).  With options.skin (default: automatic) the cells are sized rc + skin, the lists reach rc + skin and the interval opens up;
+    skin < 0 gives the old behaviour back.  Both against the oracle; the sizes the engine reports are the ones it was asked for."""
+    rc = 8.5
+    case = inputs.lj_case((9, 9, 9), a=6 * rc / 9, seed=77, rc=rc, cell_list=rc, vel_T=85.0)
+    a = engine(case)                               # automatic skin
+    b = engine(case, skin=-1.0)                    # cells exactly as control.cell_list gives them
+    c = engine(case, skin=0.6)
+    o = oracle.Oracle(case)
+    o.forces(1)
+    for n in (10, 30, 25):
+        a.step(n); b.step(n); c.step(n); o.step(n)
+    sta, stb, stc, sto = a.stats(), b.stats(), c.stats(), o.stats()
+    assert stb["n_cells"] == 6 ** 3 and stb["skin"] == 0.0 and stb["sort_interval"] == 1 and stb["pair_lists"] == 0 and stb["rebuilds"] == 65, stb
+    assert sta["n_cells"] == 5 ** 3 and 0.25 < sta["skin"] <= 0.5 and sta["sort_interval"] > 4 and sta["pair_lists"] == 1 and sta["sort_violations"] == 0, sta
+    assert sta["rebuilds"] < 30 and sta["cells_without_list"] == 0, sta
+    assert 0.6 <= stc["skin"] <= 0.76 and stc["sort_interval"] >= sta["sort_interval"] and stc["sort_violations"] == 0, stc
+    so = o.state()
+    for e in (a, b, c):
+        s, st = e.state(), e.stats()
+        for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+            assert rel_err(s[k], so[k]) < 1e-9, (k, rel_err(s[k], so[k]))
+        assert abs(st["engTot"] - sto["engTot"]) <= 1e-10 * abs(sto["engTot"])
+
+
+@pytest.mark.parametrize("kind", ["crowded_cells", "dense_wide_stencil", "sparse_cells"])
+def test_pair_lists_for_any_cell_population(kind):
+    """Lanes of k_pair_list are (atom, slice) with 64 / atoms slices per atom - not a power of two: cells of 17 - 21 atoms run three slices each, 22 - 32 two,
+    up to 64 one, a single atom eight.  'crowded_cells': cells of 1.45 rc hold 20 - 45 atoms (NS 1 - 3, lists of ~100 iterations);
+    'dense_wide_stencil': a dense liquid on cells of rc / 2.2 (7 x 7 x 7 stencil, ~900 candidates per cell: the LDS tile is several times the default);
+    'sparse_cells': a thin gas (0 - 3 atoms per cell, 8 slices per atom).  Every cell keeps its list; x / v / f against the every-step schedule and the oracle."""
+    if kind == "crowded_cells":
+        case = inputs.lj_case((12, 12, 12), a=5.6, seed=41, rc=6.0, cell_list=8.7, vel_T=150.0)
+    elif kind == "dense_wide_stencil":
+        case = inputs.lj_case((12, 12, 12), a=2.3, jitter=0.05, seed=42, rc=6.0, cell_list=2.7, vel_T=300.0)
+        case["vdw"] = [(0, 0, 1, 6.0, [0.002, 1.9])]
+    else:
+        case = inputs.lj_case((6, 6, 6), a=14.0, jitter=2.0, seed=43, rc=7.0, cell_list=7.0, vel_T=300.0)
+    a = engine(case, pair_variant=2)
+    b = engine(case, pair_variant=2, sort_every=1)
+    o = oracle.Oracle(case)
+    o.forces(1)
+    for n in (10, 30, 7):
+        a.step(n); b.step(n); o.step(n)
+    sa, sb, so, sta, stb, sto = a.state(), b.state(), o.state(), a.stats(), b.stats(), o.stats()
+    assert sta["sort_interval"] > 1 and sta["sort_violations"] == 0 and sta["pair_lists"] == 1 and sta["cells_without_list"] == 0, sta
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(sa[k], sb[k]) < 1e-9, (k, rel_err(sa[k], sb[k]))
+        assert rel_err(sa[k], so[k]) < 1e-9, (k, rel_err(sa[k], so[k]))
+    for k in ("engVdW", "engKin", "engTot"):
+        assert abs(sta[k] - stb[k]) <= 1e-10 * max(abs(stb[k]), 1e-3), (k, sta[k], stb[k])
+    assert abs(sta["engTot"] - sto["engTot"]) <= 1e-10 * abs(sto["engTot"])
+
+
+def test_lists_grow_when_cells_do_not_fit():
+    """The capacities of the lists come from the mean density; a system that is twice as dense in one half of the box overflows them there.  Such cells keep
+    no list for one interval (the clean-up launch serves them: still exact), the engine grows the lists at its next look, and from then on every cell has one."""
+    case = inputs.lj_case((12, 6, 6), a=5.6, seed=45, rc=6.5, cell_list=6.5, vel_T=60.0)
+    x = case["x"]
+    L = case["box"][0]
+    # squeeze the right half of the atoms into the right third of the box: ~1.9 x the mean density there
+    right = x > 0.5 * L
+    case["x"] = np.where(right, L * (2.0 / 3.0) + (x - 0.5 * L) * (2.0 / 3.0), x * (4.0 / 3.0))
+    case["x"] = np.round(np.clip(case["x"], 0.0, L - 1e-6), 6)
+    case["vdw"] = [(0, 0, 1, 6.5, [0.0005, 2.2])]        # soft, small atoms: the squeeze must not blow the system up
+    a = engine(case, pair_variant=2)
+    b = engine(case, pair_variant=2, sort_every=1)
+    unlisted = []
+    for n in (8, 8, 8, 30, 30):
+        a.step(n); b.step(n)
+        unlisted.append(a.stats()["cells_without_list"])
+    sa, sb, sta = a.state(), b.state(), a.stats()
+    assert sta["pair_lists"] == 1 and unlisted[-1] == 0, (unlisted, sta)
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
+        assert rel_err(sa[k], sb[k]) < 1e-9, (k, rel_err(sa[k], sb[k]))
+
+
+@pytest.mark.parametrize("kind", ["radi", "nose", "nve_lazy"])
+def test_restart_continues_exactly(kind):
+    """Checkpoint row of SURVEY section 5: state() + clock() of a running engine put into a NEW engine (set_state incl. U and radius, set_clock: step number =
+    equilibration schedule + key of the thermostat's counter-based random numbers, Nose-Hoover pair, last kinetic energy) continue the run exactly.
+    With the reference's every-step schedule the continuation is bit-identical; with the lazy schedule the restarted engine rebuilds its cells at another
+    step than the original did, so the sums differ in order (1e-11)."""
+    if kind == "radi":
+        case = inputs.lj_case((6, 6, 6), a=5.4, seed=51, rc=6.5, cell_list=6.5, T=300.0, tstat="radi", vel_T=200.0, nEq=30, freqEq=5)
+        kw = dict(sort_every=1)
+    elif kind == "nose":
+        case = inputs.lj_case((6, 6, 6), a=5.4, seed=52, rc=6.5, cell_list=6.5, T=150.0, vel_T=100.0, nEq=30, freqEq=5)
+        case.update(tstat_type=1, tau=0.05)
+        kw = dict(sort_every=1)
+    else:
+        case = inputs.lj_case((8, 8, 8), a=5.6, seed=53, rc=7.5, cell_list=7.5, vel_T=120.0)
+        kw = {}
+    a = engine(case, **kw)
+    a.step(22)
+    s, clk, st22 = a.state(), a.clock(), a.stats()
+    assert clk["step"] == 22
+    a.step(31)
+    b = engine(case, **kw)
+    b.set_state(**{k: s[k] for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz", "U", "radius")})
+    b.set_clock(**clk)
+    b.step(31)
+    sa, sb, sta, stb = a.state(), b.state(), a.stats(), b.stats()
+    assert sta["step"] == stb["step"] == 53
+    for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz", "U", "radius"):
+        if kind == "nve_lazy":
+            assert rel_err(sa[k], sb[k]) < 1e-11 or np.abs(sa[k]).max() == 0, (k, rel_err(sa[k], sb[k]))
+        else:
+            assert np.array_equal(sa[k], sb[k]), (k, rel_err(sa[k], sb[k]))
+    for k in ("engKin", "engVdW", "engTemp", "nose_chit", "nose_conint"):
+        assert abs(sta[k] - stb[k]) <= 1e-11 * max(abs(sta[k]), 1e-6), (k, sta[k], stb[k])
+
+
+def test_pressure_from_wall_momentum():
+    """aztot_stats.pressure: the serial path's wall-momentum pressure over the last `stat` window, P = 2 x 1.58e6 x dMom / (dt x area) per face
+    (main.cpp:143-163; GPU path main.cu:135-155), averaged over the six faces - asserted against the same formula applied to the ORACLE's wall momenta
+    (box.cpp:230-295) over three consecutive windows of a hot gas in an anisotropic box."""
+    case = inputs.lj_case((6, 5, 7), a=6.0, seed=61, rc=6.5, cell_list=6.5, vel_T=2500.0)
+    case["stat"] = 20
+    e = engine(case)
+    o = oracle.Oracle(case)
+    o.forces(1)
+    Lx, Ly, Lz = case["box"]
+    rev_area = [1.0 / (Ly * Lz)] * 2 + [1.0 / (Lx * Lz)] * 2 + [1.0 / (Lx * Ly)] * 2
+    keys = ("momXn", "momXp", "momYn", "momYp", "momZn", "momZp")
+    prev = [0.0] * 6
+    seen = []
+    for w in range(3):
+        e.step(20); o.step(20)
+        st, sto = e.stats(), o.stats()
+        now = [sto[k] for k in keys]
+        want = sum(2.0 * 1.58e6 * ra * (m1 - m0) / (20 * case["dt"]) for ra, m1, m0 in zip(rev_area, now, prev)) / 6.0
+        prev = now
+        assert want > 0.0
+        assert abs(st["pressure"] - want) <= 1e-9 * abs(want), (w, st["pressure"], want)
+        seen.append(st["pressure"])
+    assert len(set(seen)) == 3          # a new window every time
+    e.step(7)
+    assert e.stats()["pressure"] == seen[-1]          # inside a window the last value stands (the reference prints it every `stat` steps only)

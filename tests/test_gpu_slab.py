@@ -35,6 +35,16 @@ def run_ranks(nranks, name, nsteps, extra=None, port=29611, transport=None):
     return out
 
 
+def test_torch_in_the_process_is_what_rccl_cannot_live_with():
+    """Why the rank processes (bench.py, slab_worker.py) do not import torch: documents the observation the control plane of aztotmd_amd.ctl rests on.
+    Either outcome is accepted - the test records which one this image shows - but libaztot's own RCCL bring-up without torch must work."""
+    code = "import sys; sys.path.insert(0, %r); from aztotmd_amd import api; api.rccl_selftest(0); print('OK')" % os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    r2 = subprocess.run([sys.executable, "-c", "import torch; torch.cuda.is_available(); " + code], capture_output=True, text=True, timeout=300)
+    print("RCCL self-test with torch imported and CUDA initialised first: rc", r2.returncode, r2.stderr[-300:])
+
+
 @pytest.mark.parametrize("nranks,name,nsteps,port", [(2, "lj", 40, 29611), (3, "fennel", 25, 29612), (4, "hot", 60, 29613), (2, "thermo", 20, 29614), (2, "nose", 15, 29616),
                                                      (2, "mol", 60, 29617), (3, "mol", 30, 29618), (2, "ewald", 30, 29619)])
 def test_slabs_match_single_rank(nranks, name, nsteps, port):
@@ -84,6 +94,16 @@ def test_slabs_with_shared_tile_kernel(name, nranks, port):
     """pair_variant 3 (four waves share a tile of cell bins; opt-in) on slab ranks: ghost layers are binned like owned ones"""
     out = run_ranks(nranks, name, 15, extra={"pair_variant": 3}, port=port)
     assert out["every_atom_owned_once"] and out["max_rel_err_vs_single"] < 1e-9, out["errs"]
+
+
+def test_neighbours_that_disagree_about_their_boundary_atoms_fail_before_any_plain_exchange():
+    """RCCL first-contact hardening: behind every sort that opens an interval of plain steps the ranks exchange {atoms I will send you per plain step,
+    ghosts I hold on your side} (fixed-size messages, Exchanger::exchange_counts) and compare them with their own ranges BEFORE the first plain step
+    posts a send / receive whose counts each rank derives locally (RcclExchanger::exchange_ranges would hang or deliver coordinates to the wrong atoms on a
+    mismatch).  Here the callback transport of rank 0 lies by one atom: both ranks of the boundary must come back with AZTOT_ERR_COMM."""
+    out = run_ranks(2, "lj", 40, port=29690, transport="callback_corrupt")
+    assert out["codes"] == [-5, -5], out
+    assert "disagree about their boundary atoms" in out["message"], out
 
 
 def test_rccl_library_selftest():
