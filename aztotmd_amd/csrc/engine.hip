@@ -1394,9 +1394,9 @@ void Engine::adapt_sort_interval()
             // LDS per wave is what bounds the occupancy of k_pair_list: the tiles are sized from the largest cell ever recorded (+ 6 %), not from the
             // capacity of the arrays.  A cell that does not fit next time keeps no list for one interval (exact: the clean-up launch serves it) and is
             // counted; then the tiles grow again.
-            int candLds = std::max(kListMinCand, std::min(candCap_, (nl[3] + nl[3] / 16 + 8 + 63) & ~63));
+            int candLds = std::max(4 * kWave, std::min(candCap_, (nl[3] + nl[3] / 25 + 6 + 7) & ~7));
             int iterLds = std::max(2 * kListMinIter, std::min(iterCap_, (nl[4] + nl[4] / 8 + 2 + 7) & ~7));
-            if (nl[5] > 0) candLds = std::min(candCap_, std::max(candLds, candLds_ + 64));
+            if (nl[5] > 0) candLds = std::min(candCap_, std::max(candLds, candLds_ + 32));
             if (nl[6] > 0) iterLds = std::min(iterCap_, std::max(iterLds, iterLds_ + 8));
             if (debug_ & 65536) { candLds = candLds_; iterLds = iterLds_; }
             const bool capFull = (nl[5] > 0 && candLds_ == candCap_) || (nl[6] > 0 && iterLds_ == iterCap_);

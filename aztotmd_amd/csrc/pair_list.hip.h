@@ -148,6 +148,8 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
                 return c;
             };
             auto put = [&](int u, uint32_t e, const Cand& c) {
+                // (the tile holds candLds records, not whole groups of 64: LDS per wave bounds the occupancy; the first four groups always fit)
+                if (u >= 4 && u * kWave + lane >= L.candLds) return;
                 double xj = c.x, yj = c.y, zj = c.z;
                 if (images)
                 {   // image code per axis: 0 -> -L, 1 -> 0, 2 -> +L (exact: the product is +-L or 0)
@@ -324,10 +326,10 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 struct BuildLds
 {
-    int capS;            // floats per coordinate array: candLds + 16 (the matrix filter reads whole blocks of 16)
-    int nWords;          // 32-bit hit-mask words per lane and atom group: ceil(capS / 128)
+    int capS;            // floats per coordinate array: candLds rounded up to whole mask words (the matrix filter reads 8 blocks of 16 candidates at a time)
+    int nWords;          // 32-bit hit-mask words per lane and atom group: capS / 128
     int hitCap;          // entries of the compact hit array: iterLds x 64
-    __host__ __device__ BuildLds(int candLds, int iterLds) : capS(candLds + 16), nWords((candLds + 16 + 127) / 128), hitCap(iterLds * kWave) {}
+    __host__ __device__ BuildLds(int candLds, int iterLds) : capS((candLds + 127) & ~127), nWords((candLds + 127) / 128), hitCap(iterLds * kWave) {}
     __host__ __device__ size_t union_bytes() const { const size_t a = sizeof(uint32_t) * (size_t)capS, b = sizeof(uint16_t) * (size_t)hitCap; return ((a > b ? a : b) + 15) & ~(size_t)15; }
     __host__ __device__ size_t bytes() const { return sizeof(float) * 4 * (size_t)capS + union_bytes() + sizeof(uint32_t) * (size_t)nWords * kWave; }
 };
@@ -469,8 +471,8 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
         const int Tpad = (T + kWave - 1) & ~(kWave - 1);
         for (int q = lane; q < Tpad; q += kWave) myList[q] = (q < T) ? tent[q] : ((uint32_t)ib | (0x15u << 26));
     }
-    // far-away, finite dummies behind the last candidate: the filter reads whole blocks of 16
-    if (lane < 16) { tx[T + lane] = -1e30f; ty[T + lane] = 0.0f; tz[T + lane] = 0.0f; tw[T + lane] = -3e38f; }
+    // far-away, finite dummies behind the last candidate up to the end of its mask word: the filter reads whole words of 8 x 16 candidates, without guards
+    for (int q = T + lane; q < ((T + 127) & ~127); q += kWave) { tx[q] = -1e30f; ty[q] = 0.0f; tz[q] = 0.0f; tw[q] = -3e38f; }
     // where the cell's own atoms sit in the tile (they are candidates too, unshifted): found by their list entries
     for (int q = lane; q < T; q += kWave)
     {
@@ -508,26 +510,29 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
         int h = 0;
         for (int wd = 0; wd < nW; wd++)
         {
-            uint32_t miss = 0xFFFFFFFFu;                              // one bit per candidate of the lane, 1 = outside; newest candidate in bit 0
-            const int nb = min(8, nBlk - 8 * wd);
+            // all operands of the word's eight blocks first (the tile is padded with dummies to the end of the word), then the eight matrix instructions,
+            // then the sign bits: no guards, so the reads of one block do not wait for the arithmetic of the one before
+            float av[8];
+            float4_t cw[8];
 #pragma unroll
             for (int q = 0; q < 8; q++)
             {
-                if (q < nb)
-                {
-                    const int o = (8 * wd + q) * 16;
-                    const float av = pa[o];
-                    const float aop = (kq == 3) ? 1.0f : av;
-                    const float4_t cw = {pc[o], pc[o + 4], pc[o + 8], pc[o + 12]};
-                    const float4_t d = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, fB, cw, 0, 0, 0);
-                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[0]), 31);
-                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[1]), 31);
-                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[2]), 31);
-                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[3]), 31);
-                }
+                const int o = (8 * wd + q) * 16;
+                av[q] = pa[o];
+                cw[q] = float4_t{pc[o], pc[o + 4], pc[o + 8], pc[o + 12]};
             }
-            // left-aligned: candidate number p of this word (p = 4 (block & 7) + r) sits at bit 31 - p
-            uint32_t m = ~miss << (32 - 4 * nb);
+            uint32_t miss = 0u;                                      // one bit per candidate of the lane, 1 = outside; newest candidate in bit 0
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+            {
+                const float4_t d = __builtin_amdgcn_mfma_f32_16x16x4f32((kq == 3) ? 1.0f : av[q], fB, cw[q], 0, 0, 0);
+                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[0]), 31);
+                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[1]), 31);
+                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[2]), 31);
+                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[3]), 31);
+            }
+            // candidate number p of this word (p = 4 (block & 7) + r) sits at bit 31 - p; the dummies behind the last candidate are misses
+            uint32_t m = ~miss;
             // the atom itself is a candidate of its own tile (always a hit): not a partner
             if (kSelf >= 0 && (kSelf & 3) == kq && (kSelf >> 7) == wd) m &= ~(0x80000000u >> ((kSelf & 127) >> 2));
             maskBuf[wd * kWave + lane] = m;
@@ -567,6 +572,7 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if ((P.pad0 & 3) >= 2) return;                                 // (phase timing: no read-out)
     nIter = wave_max_int(nIter);
     // (debug bit 65536, tests: lists hold 14 iterations only - part of a liquid's cells then keep no list and go through the clean-up launch)
     const bool usable = !tooLong && nIter <= ((P.pad0 & 65536) ? 14 : L.iterCap);

@@ -384,7 +384,7 @@ struct PairLists
                                    //      fit the tile / the list since the host last looked ; [8..10] statistics (debug)
     int32_t candCap = 0;           // candidates per cell in `cand` (multiple of 64)
     int32_t iterCap = 0;           // list iterations per cell in `pairs` (multiple of 8)
-    int32_t candLds = 0;           // candidates the LDS tiles of k_pair_list / k_build_lists hold (multiple of 64, <= candCap): sized by the engine from the largest T
+    int32_t candLds = 0;           // candidates the LDS tiles of k_pair_list / k_build_lists hold (>= 256, <= candCap): sized by the engine from the largest T
                                    //      seen, because LDS per wave is what bounds the occupancy of k_pair_list (7.7 KiB: 95 us, 10.8 KiB: 106 us on the 1 M-atom box)
     int32_t iterLds = 0;           // iterations the builder's LDS list buffer holds (multiple of 8, <= iterCap)
     int32_t recBytes = 0;          // bytes per LDS record in k_pair_list: 24 {x, y, z} or 32 {x, y, z, radius}
