@@ -157,6 +157,7 @@ private:
     float4* dRel_ = nullptr;        // [capacity + 64] position relative to the own cell's centre (f32) + cell z index, written by the sort for the list builder
     int candCap_ = 0, iterCap_ = 0; // capacities of the lists per cell (PairLists); grown when too many cells turn out not to fit
     int listGrowths_ = 0;
+    int listWaves_ = 1;             // waves per cell in k_pair_list (PairLists::waves)
     size_t listLdsMax_ = 0;         // dynamic LDS this device grants a workgroup
     void allocate_lists(int candCap, int iterCap);
     void free_lists();

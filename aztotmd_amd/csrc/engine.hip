@@ -429,7 +429,7 @@ void Engine::allocate()
         split_.n = n;
         split_.capacity = capacity_;
     }
-    pairBlocks_ = std::max(div_up(capacity_, kBlock), pair_tile_grid(P_) * split_.n + 24 + 3 * pair_cleanup_grid(pair_tile_cells(P_)));
+    pairBlocks_ = std::max(div_up(capacity_, kBlock), pair_tile_grid(P_) * std::max(split_.n, kListMaxWaves) + 24 + 3 * pair_cleanup_grid(pair_tile_cells(P_)));
     maxBlocks_ = std::max(div_up(capacity_, kBlock), pairBlocks_) + 1;
     auto alloc = [&](size_t bytes) { void* p = nullptr; HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16))); allocs_.push_back(p); return p; };
     const size_t nd = sizeof(double) * (size_t)capacity_, ni = sizeof(int32_t) * (size_t)capacity_;
@@ -528,7 +528,23 @@ void Engine::allocate()
                 const int nBig = std::min(kWave, (int)(1.6 * perCell) + 6);
                 int cand = (int)(density * vol * 1.5) + 64;
                 int iters = (int)(partners * 1.25 / list_slices(nBig)) + 4;
-                cand = std::max(kListMinCand, (cand + 63) & ~63);
+                // waves per cell in k_pair_list (they share the cell's tile and split its atoms): one where cells are many and their tiles small; more where the
+                // tile of a cell is large (LDS per wave bounds the occupancy: dense systems, wide stencils) - measured: M4 (28 atoms and 720 candidates per
+                // cell) 788 -> 514 us with two; on the 1 M-atom liquid (14 atoms, 320 candidates) two waves cost 102 -> 158 us: every wave pays the
+                // fixed part of a cell again
+                {
+                    const int cells = pair_tile_cells(P_);
+                    const double tileBytes = density * vol * (P_.single_lj ? 24.0 : (pair_list_tab_mode(P_) ? 25.0 : 32.0));
+                    int w = 1;
+                    (void)cells;             // (few cells alone do not pay for more waves: C2 13.9 -> 15.2 us, an emulated rank of 8 26.8 -> 29.2 us with two)
+                    if (tileBytes > 13.0 * 1024) w = 2;
+                    if (tileBytes > 26.0 * 1024) w = 4;
+                    if (opt_.waves_per_cell == 1 || opt_.waves_per_cell == 2 || opt_.waves_per_cell == 4) w = opt_.waves_per_cell;
+                    listWaves_ = w;
+                    // (a wave of a W-wave cell serves ceil(n / W) atoms: sized for a cell 60 % fuller than the mean, as above)
+                    iters = (int)(partners * 1.25 / list_slices(list_atoms_per_wave(std::min(kWave * w, (int)(1.6 * perCell) + 6), w))) + 4;
+                }
+                cand = std::max(kListMinCand * listWaves_, (cand + 63) & ~63);
                 iters = std::max(2 * kListMinIter, (iters + 7) & ~7);
                 if (const char* e = std::getenv("AZTOT_CAND_CAP")) cand = std::atoi(e);        // (experiments)
                 if (const char* e = std::getenv("AZTOT_ITER_CAP")) iters = std::atoi(e);
@@ -561,7 +577,7 @@ void Engine::allocate_lists(int candCap, int iterCap)
     candCap = std::min(candCap, kListCandMax);
     iterCap = std::min(iterCap, kListIterMax);
     PairLists probe;
-    probe.candCap = probe.candLds = candCap; probe.iterCap = probe.iterLds = iterCap; probe.recBytes = pair_list_rec_bytes(P_);
+    probe.candCap = probe.candLds = candCap; probe.iterCap = probe.iterLds = iterCap; probe.recBytes = pair_list_rec_bytes(P_); probe.waves = listWaves_;
     while (candCap > kListMinCand && (pair_list_lds_bytes(P_, probe) > listLdsMax_ || build_lists_lds_bytes(probe) > listLdsMax_))
     {
         candCap -= 64;
@@ -572,7 +588,7 @@ void Engine::allocate_lists(int candCap, int iterCap)
     auto alloc = [&](size_t bytes) { void* p = nullptr; HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16))); return p; };
     dCandList_ = (uint32_t*)alloc(sizeof(uint32_t) * nc * candCap);
     dListMeta_ = (int32_t*)alloc(sizeof(int32_t) * 2 * nc);
-    dPairList_ = (uint16_t*)alloc(sizeof(uint16_t) * nc * (size_t)iterCap * kWave);
+    dPairList_ = (uint16_t*)alloc(sizeof(uint16_t) * nc * (size_t)listWaves_ * (size_t)iterCap * kWave);
     dNoList_ = (int32_t*)alloc(sizeof(int32_t) * 16);
     dRel_ = (float4*)alloc(sizeof(float4) * ((size_t)capacity_ + kWave));
     HIP_CHECK(hipMemsetAsync(dRel_, 0, sizeof(float4) * ((size_t)capacity_ + kWave), stream_));
@@ -590,7 +606,7 @@ void Engine::allocate_lists(int candCap, int iterCap)
         HIP_CHECK(hipStreamSynchronize(stream_));
     }
     HIP_CHECK(hipMemsetAsync(dCandList_, 0, sizeof(uint32_t) * nc * candCap, stream_));      // every entry is an atom index at all times
-    HIP_CHECK(hipMemsetAsync(dPairList_, 0, sizeof(uint16_t) * nc * (size_t)iterCap * kWave, stream_));   // every entry is a tile offset at all times (k_pair_list reads ahead)
+    HIP_CHECK(hipMemsetAsync(dPairList_, 0, sizeof(uint16_t) * nc * (size_t)listWaves_ * (size_t)iterCap * kWave, stream_));   // every entry is a tile offset at all times (k_pair_list reads ahead)
     HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(int32_t) * 16, stream_));
     listsOn_ = true;
     listsValid_ = false;
@@ -618,7 +634,7 @@ PairLists Engine::pair_lists() const
     if (listsOn_)
     {
         pl.cand = dCandList_; pl.meta = dListMeta_; pl.pairs = dPairList_; pl.noList = dNoList_;
-        pl.candCap = candCap_; pl.iterCap = iterCap_; pl.candLds = candLds_; pl.iterLds = iterLds_; pl.recBytes = pair_list_rec_bytes(P_); pl.entryScale = pair_list_entry_scale(P_);
+        pl.candCap = candCap_; pl.iterCap = iterCap_; pl.candLds = candLds_; pl.iterLds = iterLds_; pl.recBytes = pair_list_rec_bytes(P_); pl.entryScale = pair_list_entry_scale(P_); pl.waves = listWaves_;
         pl.rel = dRel_;
     }
     return pl;
@@ -1394,7 +1410,7 @@ void Engine::adapt_sort_interval()
             // LDS per wave is what bounds the occupancy of k_pair_list: the tiles are sized from the largest cell ever recorded (+ 6 %), not from the
             // capacity of the arrays.  A cell that does not fit next time keeps no list for one interval (exact: the clean-up launch serves it) and is
             // counted; then the tiles grow again.
-            int candLds = std::max(4 * kWave, std::min(candCap_, (nl[3] + nl[3] / 25 + 6 + 7) & ~7));
+            int candLds = std::max(kWave, std::min(candCap_, (nl[3] + nl[3] / 25 + 6 + 7) & ~7));
             int iterLds = std::max(2 * kListMinIter, std::min(iterCap_, (nl[4] + nl[4] / 8 + 2 + 7) & ~7));
             if (nl[5] > 0) candLds = std::min(candCap_, std::max(candLds, candLds_ + 32));
             if (nl[6] > 0) iterLds = std::min(iterCap_, std::max(iterLds, iterLds_ + 8));

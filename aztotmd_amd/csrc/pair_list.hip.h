@@ -24,33 +24,40 @@ namespace aztot {
 constexpr int kListPreload = 5;            // groups of 64 candidate entries every wave of k_pair_list asks for before it knows the cell's T (candCap >= 320)
 constexpr int kListMinCand = 64 * kListPreload;
 constexpr int kListMinIter = 16;           // two chunks of 8 iterations are asked for up front
-constexpr int kListMaxSlices = 8;
+constexpr int kListMaxSlices = 32;         // slices per atom (a cell of one or two atoms still uses half a wave)
 
-__host__ __device__ inline int list_slices(int nAtoms) { const int n = kWave / (nAtoms > 0 ? nAtoms : 1); return n > kListMaxSlices ? kListMaxSlices : (n < 1 ? 1 : n); }
+constexpr int kListMaxWaves = 4;
+// a cell of n atoms served by W waves: every wave takes ceil(n / W) atoms (the last ones fewer, possibly none), each with NS = 64 / that many slices
+__host__ __device__ inline int list_atoms_per_wave(int nAtoms, int W) { return (nAtoms + W - 1) / W; }
+__host__ __device__ inline int list_slices(int nAtomsOfWave) { const int n = kWave / (nAtomsOfWave > 0 ? nAtomsOfWave : 1); return n > kListMaxSlices ? kListMaxSlices : (n < 1 ? 1 : n); }
 
 // LDS of k_pair_list by kernel mode (LDS per wave bounds its occupancy, so every byte per candidate counts):
 //   one species, LJ (MODE 1)            records {x, y, z} of 24 B; a list entry is the record's byte offset
 //   table-driven modes (2, 3, 5)        [pair table 1 KiB][species bytes, kListTypeBytes][records of 24 B]; a list entry is the record NUMBER (the species byte
 //                                       sits at a fixed offset + number, the record at number x 24 + base: one v_mad more per visit, 8 B less per candidate)
-//   radii (MODE 4) / generic (MODE 0)   records {x, y, z, radius} of 32 B, entry = byte offset [+ species bytes behind the records]
+//   radii (MODE 4) / generic (MODE 0)   [records of 24 B][radii, 8 B each][species bytes (MODE 0)]; entry = record number.  (Records of 32 B {x, y, z, radius}
+//                                       were tried first: a stride of 8 banks leaves 8 distinct bank groups for 64 lanes - 90 % of the LDS cycles of the
+//                                       case-study-2 kernel were bank conflicts; 24 B = 6 banks gives 32)
 inline bool pair_list_tab_mode(const StepParams& P) { return P.pad1 == 2 && !P.single_lj; }
 inline size_t pair_list_lds_bytes(const StepParams& P, const PairLists& L)
 {
     const bool tab = pair_list_tab_mode(P);
     const bool generic = !P.single_lj && P.pad1 != 2 && P.pad1 != 4;
-    size_t b = (size_t)(L.candLds + 1) * L.recBytes;
+    const bool radii = !P.single_lj && !tab;                       // MODE 4 and MODE 0
+    size_t b = (size_t)(L.candLds + 1) * 24;
     if (tab) b += sizeof(double) * kLjSpecMax * kLjSpecMax * kPairTabStride + (((size_t)L.candLds + 1 + 15) & ~(size_t)15);
+    if (radii) b += sizeof(double) * (size_t)(L.candLds + 1);
     if (generic) b += (size_t)(L.candLds + 1 + 7) & ~(size_t)7;
     return b;
 }
-inline int pair_list_rec_bytes(const StepParams& P) { return (P.single_lj || pair_list_tab_mode(P)) ? 24 : 32; }
-inline int pair_list_entry_scale(const StepParams& P) { return pair_list_tab_mode(P) ? 1 : pair_list_rec_bytes(P); }     // what the builder multiplies a record number by
+inline int pair_list_rec_bytes(const StepParams&) { return 24; }
+inline int pair_list_entry_scale(const StepParams& P) { return P.single_lj ? 24 : 1; }     // what the builder multiplies a record number by: byte offset, or the number itself
 
 // ENG = false: the launch books no energies (steps whose energies nobody can see: all but the last step of an aztot_step call - the statistics are those of
 // the last step, finish_steps; the reference prints them every `stat` steps, cuStat.cu:308-330).  Forces are the same instructions either way: the energy
 // terms feed nothing else, the compiler drops them and their two wave reductions.
 template <int MODE, int VDW, bool ENG>
-__global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
+__global__ __launch_bounds__(kWave * kListMaxWaves) void k_pair_list(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase, PairLists L,
                                                      NextStep N)
@@ -58,16 +65,18 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     constexpr bool kOneSpecies = (MODE == 1 || MODE == 4);           // no species table, no type ids
     constexpr bool kRadii = (MODE == 0 || MODE == 4);
     constexpr bool kTab = (MODE == 2 || MODE == 3 || MODE == 5);
-    constexpr int RECB = (MODE == 1 || kTab) ? 24 : 32;              // record {x, y, z [, radius]} RELATIVE to the centre of the cell
-    constexpr int ESCALE = kTab ? 24 : 1;                            // list entry -> byte offset of the record (table modes keep record numbers)
+    constexpr int RECB = 24;                                         // record {x, y, z} RELATIVE to the centre of the cell
+    constexpr int ESCALE = (MODE == 1) ? 1 : 24;                     // list entry -> byte offset of the record (only the one-species LJ kernel keeps byte offsets)
     constexpr int kTabDoubles = kTab ? kLjSpecMax * kLjSpecMax * kPairTabStride : 0;
     extern __shared__ double ldsList[];
     double* const pairTab = ldsList;
     uint8_t* const ttypT = (uint8_t*)(ldsList + kTabDoubles);        // table modes: species ids by record number, at a compile-time offset
     char* const tb = (char*)(ldsList + kTabDoubles) + (kTab ? ((L.candLds + 1 + 15) & ~15) : 0);
-    uint8_t* const ttyp0 = (uint8_t*)(tb + (size_t)(L.candLds + 1) * RECB);      // MODE 0 only: species ids (by record number)
+    double* const trad = (double*)(tb + (size_t)(L.candLds + 1) * RECB);         // MODE 0 / 4: radii (by record number)
+    uint8_t* const ttyp0 = (uint8_t*)(trad + (L.candLds + 1));                   // MODE 0 only: species ids (by record number)
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int W = L.waves;                                           // waves of this workgroup = waves per cell (they share the tile, each serves its share of the atoms)
     const int per = (nCellsRun + 7) >> 3;
     const int cr = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware: each XCD owns a contiguous eighth of the cells
     double eV = 0.0, eC = 0.0, dropped = 0.0, eK = 0.0;
@@ -79,11 +88,12 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     // arrays whatever they return): list header, five groups of candidate entries, the lane's first two list chunks.  A wave's life is then two
     // memory round trips (these, then the coordinates) and the loop
     const int cell = firstCell + min(cr, nCellsRun - 1);
+    // (candidate groups are dealt to the waves round-robin: wave w gathers groups w, w + W, ...; candCap >= 64 * 5 * W keeps the five preloads inside the array)
     const uint32_t* const myList = L.cand + (size_t)cell * L.candCap + lane;
-    const uint4* const pl = (const uint4*)(L.pairs + (size_t)cell * L.iterCap * kWave) + lane;
+    const uint4* const pl = (const uint4*)(L.pairs + ((size_t)cell * W + wave) * L.iterCap * kWave) + lane;
     uint32_t ent[kListPreload];
 #pragma unroll
-    for (int u = 0; u < kListPreload; u++) ent[u] = myList[u * kWave];
+    for (int u = 0; u < kListPreload; u++) ent[u] = myList[(wave + u * W) * kWave];
     uint4 w = pl[0];
     uint4 w1 = pl[kWave];                                           // (the second chunk too: 16 iterations cover a liquid's cells, and a chunk asked for only
                                                                     //  8 iterations ahead arrives late)
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         if (kTab)
         {
             const int np = P.nSpec * P.nSpec;
-            if (lane < np)
+            if (threadIdx.x < np)
             {
                 const DevPot v = pots[lane];
                 const int a = lane / P.nSpec, b = lane - a * P.nSpec;
@@ -113,13 +123,15 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
                 q[7] = (double)v.type;
             }
         }
-        // ---- the cell's own atoms: lane = slot * NS + slice
-        const int nthis = ie - ib;                                     // 1 .. 64 (cells with more keep no list)
-        const int NS = list_slices(nthis);
+        // ---- the cell's own atoms: this wave serves atoms [wave * aw, wave * aw + aw) of the cell; lane = slot * NS + slice
+        const int ncell = ie - ib;                                     // 1 .. 64 W (cells with more keep no list)
+        const int aw = list_atoms_per_wave(ncell, W);
+        const int nthis = max(0, min(aw, ncell - wave * aw));           // atoms of this wave (the last waves of a small cell may have none)
+        const int NS = list_slices(aw);
         const int rcpNS = 65536 / NS + 1;
         const int slot = (lane * rcpNS) >> 16, slice = lane - slot * NS;
         const bool validI = slot < nthis;
-        const int myi = ib + slot;
+        const int myi = ib + wave * aw + slot;
         // (every lane loads - idle atom slots from the cell's first atom - so that the three loads travel together; a conditional load made the compiler
         //  wait for each of them in turn)
         const int myl = validI ? myi : ib;
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
             };
             auto put = [&](int u, uint32_t e, const Cand& c) {
                 // (the tile holds candLds records, not whole groups of 64: LDS per wave bounds the occupancy; the first four groups always fit)
-                if (u >= 4 && u * kWave + lane >= L.candLds) return;
+                if (u * kWave + lane >= L.candLds) return;
                 double xj = c.x, yj = c.y, zj = c.z;
                 if (images)
                 {   // image code per axis: 0 -> -L, 1 -> 0, 2 -> +L (exact: the product is +-L or 0)
@@ -160,42 +172,43 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
                 char* const r = tb + (size_t)(u * kWave + lane + 1) * RECB;       // candidate k -> record k + 1 (record 0 is the dummy)
                 *(double*)r = xj - cc0; *(double*)(r + 8) = yj - cc1; *(double*)(r + 16) = zj - cc2;
                 if (kTab) ttypT[u * kWave + lane + 1] = (uint8_t)c.typ;
-                if (kRadii) *(double*)(r + 24) = c.rad;
+                if (kRadii) trad[u * kWave + lane + 1] = c.rad;
                 if (MODE == 0) ttyp0[u * kWave + lane + 1] = (uint8_t)c.typ;
             };
+            // this wave's groups are wave + q W, q = 0, 1, ...
             const Cand c0 = fetch(ent[0]), c1 = fetch(ent[1]), c2 = fetch(ent[2]), c3 = fetch(ent[3]);
-            if (T > 4 * kWave)
+            if (T > 4 * W * kWave)
             {
                 const Cand c4 = fetch(ent[4]);
-                put(0, ent[0], c0); put(1, ent[1], c1); put(2, ent[2], c2); put(3, ent[3], c3); put(4, ent[4], c4);
+                put(wave, ent[0], c0); put(wave + W, ent[1], c1); put(wave + 2 * W, ent[2], c2); put(wave + 3 * W, ent[3], c3); put(wave + 4 * W, ent[4], c4);
                 // dense systems: the rest of the tile, four groups per round trip
-                for (int u0 = kListPreload; u0 * kWave < T; u0 += 4)
+                for (int q0 = kListPreload; (wave + q0 * W) * kWave < T; q0 += 4)
                 {
                     uint32_t en[4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) en[q] = ((u0 + q) * kWave < T) ? myList[(u0 + q) * kWave] : ent[0];
+                    for (int q = 0; q < 4; q++) en[q] = ((wave + (q0 + q) * W) * kWave < T) ? myList[(wave + (q0 + q) * W) * kWave] : ent[0];
                     const Cand d0 = fetch(en[0]), d1 = fetch(en[1]), d2 = fetch(en[2]), d3 = fetch(en[3]);
-                    put(u0, en[0], d0);
-                    if ((u0 + 1) * kWave < T) put(u0 + 1, en[1], d1);
-                    if ((u0 + 2) * kWave < T) put(u0 + 2, en[2], d2);
-                    if ((u0 + 3) * kWave < T) put(u0 + 3, en[3], d3);
+                    put(wave + q0 * W, en[0], d0);
+                    if ((wave + (q0 + 1) * W) * kWave < T) put(wave + (q0 + 1) * W, en[1], d1);
+                    if ((wave + (q0 + 2) * W) * kWave < T) put(wave + (q0 + 2) * W, en[2], d2);
+                    if ((wave + (q0 + 3) * W) * kWave < T) put(wave + (q0 + 3) * W, en[3], d3);
                 }
             }
-            else { put(0, ent[0], c0); put(1, ent[1], c1); put(2, ent[2], c2); put(3, ent[3], c3); }
+            else { put(wave, ent[0], c0); put(wave + W, ent[1], c1); put(wave + 2 * W, ent[2], c2); put(wave + 3 * W, ent[3], c3); }
         }
         // idle atom slots sit far away on the other side of the dummy candidate, so that nothing they meet is inside a cut-off
         const double xi = validI ? xr - cc0 : 1e30, yi = validI ? yr - cc1 : 1e30, zi = validI ? zr - cc2 : 1e30;
         // the dummy candidate the unused list entries (0) point at: far outside any cut-off, with a species and a radius the potentials can digest
         constexpr uint32_t dummyOff = 0u;
-        if (lane == 0)
+        if (threadIdx.x == 0)
         {
             char* const r = tb;
             *(double*)r = -1e30; *(double*)(r + 8) = -1e30; *(double*)(r + 16) = -1e30;
             if (kTab) ttypT[0] = 0;
-            if (kRadii) *(double*)(r + 24) = 1.0;
+            if (kRadii) trad[0] = 1.0;
             if (MODE == 0) ttyp0[0] = 0;
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();                                                // (one wave: no more than the wave barrier it replaces; the branch is uniform over the workgroup)
 
         // ---- every lane walks its list
         PairAcc acc = {0, 0, 0, 0, 0, 0};
@@ -213,8 +226,8 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
             y = *(const double*)(tb + ko + 8);
             z = *(const double*)(tb + ko + 16);
             if (kTab) ty = ttypT[en];
-            if (kRadii) rd = *(const double*)(tb + ko + 24);
-            if (MODE == 0) ty = ttyp0[ko >> 5];                    // (RECB = 32: record number)
+            if (kRadii) rd = trad[en];
+            if (MODE == 0) ty = ttyp0[en];
         };
         fetch(nIter > 0 ? (w.x & 0xFFFFu) : dummyOff, xj, yj, zj, tj, radj);
         for (int c = 0; c < nChunks; c++)
@@ -242,20 +255,21 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
         }
         if (MODE != 0) acc.dropped += 0.5 * (double)nDropHalf;
 
-        // fold the slices of every atom (neighbouring lanes, fixed order: slice 0 + slice 1 + ...) and write the force: clear_force + pair sums
+        // fold the slices of every atom (neighbouring lanes) in a fixed tree order and write the force: clear_force + pair sums
         if (NS == 4)
         {   // (the usual case: two lane exchanges inside a quad)
             acc.fx += __shfl_xor(acc.fx, 1, kWave); acc.fy += __shfl_xor(acc.fy, 1, kWave); acc.fz += __shfl_xor(acc.fz, 1, kWave);
             acc.fx += __shfl_xor(acc.fx, 2, kWave); acc.fy += __shfl_xor(acc.fy, 2, kWave); acc.fz += __shfl_xor(acc.fz, 2, kWave);
         }
         else
-        {
-            const double px = acc.fx, py = acc.fy, pz = acc.fz;
-            for (int s = 1; s < NS; s++)
+        {   // n partial sums left in slices 0 .. n - 1: slice i < s takes slice i + s (if there is one), then n = s; at most five steps for 32 slices
+            int n = NS;
+            for (int s = kListMaxSlices / 2; s >= 1; s >>= 1)
             {
-                acc.fx += __shfl_down(px, s, kWave);
-                acc.fy += __shfl_down(py, s, kWave);
-                acc.fz += __shfl_down(pz, s, kWave);
+                if (s >= n) continue;                                   // wave-uniform
+                const double ux = __shfl_down(acc.fx, s, kWave), uy = __shfl_down(acc.fy, s, kWave), uz = __shfl_down(acc.fz, s, kWave);
+                if (slice < s && slice + s < n) { acc.fx += ux; acc.fy += uy; acc.fz += uz; }
+                n = s;
             }
         }
         if (validI && slice == 0)
@@ -283,9 +297,10 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     if (ENG) eV = wave_sum(eV);
     if (ENG && MODE != 1 && MODE != 4) eC = wave_sum(eC);
     if (__any(dropped != 0.0)) dropped = wave_sum(dropped);
+    // every wave books into its own partial-sum slot (fixed order of the final sums whatever W is)
+    const size_t pb = (size_t)blockBase + (size_t)blockIdx.x * W + wave;
     if (lane == 0)
     {
-        const size_t pb = (size_t)blockBase + blockIdx.x;
         if (ENG)
         {
             partials[(size_t)PS_EVDW * maxBlocks + pb] = eV;
@@ -296,15 +311,15 @@ __global__ __launch_bounds__(kWave) void k_pair_list(StepParams P, SpecTable S, 
     if (ENG && P.fuseKick)
     {
         eK = wave_sum(eK);
-        if (lane == 0) partials[(size_t)PS_EKIN * maxBlocks + blockBase + blockIdx.x] = 0.5 * eK;
+        if (lane == 0) partials[(size_t)PS_EKIN * maxBlocks + pb] = 0.5 * eK;
     }
     if (N.xn)
     {
-        next_step_finish(P, N, nacc, partials, maxBlocks, (size_t)blockBase + blockIdx.x);
+        next_step_finish(P, N, nacc, partials, maxBlocks, pb);
         // the step counter of the step being opened (main.cpp:92), and: its second half-kick is NOT owed to the next k_integrate1_bin
-        if (blockIdx.x == 0 && lane == 0) { N.st->step += 1; N.st->pendingKick = 0; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { N.st->step += 1; N.st->pendingKick = 0; }
     }
-    else if (N.pendingAfter >= 0 && blockIdx.x == 0 && lane == 0) N.st->pendingKick = N.pendingAfter;
+    else if (N.pendingAfter >= 0 && blockIdx.x == 0 && threadIdx.x == 0) N.st->pendingKick = N.pendingAfter;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
@@ -328,16 +343,19 @@ struct BuildLds
 {
     int capS;            // floats per coordinate array: candLds rounded up to whole mask words (the matrix filter reads 8 blocks of 16 candidates at a time)
     int nWords;          // 32-bit hit-mask words per lane and atom group: capS / 128
-    int hitCap;          // entries of the compact hit array: iterLds x 64
-    __host__ __device__ BuildLds(int candLds, int iterLds) : capS((candLds + 127) & ~127), nWords((candLds + 127) / 128), hitCap(iterLds * kWave) {}
+    int hitCap;          // entries of the compact hit array: iterLds x 64 x waves per cell
+    int nTab;            // entries of each of the three small tables (staging table: <= 64 runs ; per atom of the cell: <= 64 x waves)
+    __host__ __device__ BuildLds(int candLds, int iterLds, int waves)
+        : capS((candLds + 127) & ~127), nWords((candLds + 127) / 128), hitCap(iterLds * kWave * waves), nTab(kWave * waves) {}
     __host__ __device__ size_t union_bytes() const { const size_t a = sizeof(uint32_t) * (size_t)capS, b = sizeof(uint16_t) * (size_t)hitCap; return ((a > b ? a : b) + 15) & ~(size_t)15; }
-    __host__ __device__ size_t bytes() const { return sizeof(float) * 4 * (size_t)capS + union_bytes() + sizeof(uint32_t) * (size_t)nWords * kWave; }
+    __host__ __device__ size_t bytes() const { return sizeof(float) * 4 * (size_t)capS + union_bytes() + sizeof(uint32_t) * (size_t)nWords * kWave + sizeof(int32_t) * 3 * (size_t)nTab; }
 };
 
 __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun, PairLists L)
 {
     extern __shared__ float ldsBuild[];
-    const BuildLds G(L.candLds, L.iterLds);
+    const int W = L.waves;
+    const BuildLds G(L.candLds, L.iterLds, W);
     float* const tx = ldsBuild;
     float* const ty = tx + G.capS;
     float* const tz = ty + G.capS;
@@ -345,7 +363,9 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
     uint32_t* const tent = (uint32_t*)(tw + G.capS);                // list entries of the candidates (atom index | image code << 26), tile order ...
     uint16_t* const hits = (uint16_t*)tent;                         // ... and, once those have left, the compact hit array (entries of k_pair_list's lists, atom by atom)
     uint32_t* const maskBuf = (uint32_t*)((char*)tent + G.union_bytes());      // [nWords][64] hit masks of the atom group in flight
-    __shared__ int32_t entJ[kWave], entN[kWave], entC[kWave];       // staging table: first atom, count (<= 64), codes ; later: tile slot / offset / hit count per atom
+    int32_t* const entJ = (int32_t*)(maskBuf + (size_t)G.nWords * kWave);      // staging table: first atom, count (<= 64), codes ; later, per atom of the cell:
+    int32_t* const entN = entJ + G.nTab;                            //   tile slot / offset / hit count
+    int32_t* const entC = entN + G.nTab;
 
     const int lane = threadIdx.x;
     const int per = (nCellsRun + 7) >> 3;
@@ -360,7 +380,7 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
     const int nthis = ie - ib;
     if (nthis == 0) { if (lane == 0) L.meta[2 * cell] = 0; return; }            // an empty cell: a list with nothing in it
     auto no_list = [&](int why) { if (lane == 0) { L.meta[2 * cell] = -1; atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); if (why) atomicAdd(&L.noList[why], 1); } };
-    if (nthis > kWave) { no_list(0); return; }
+    if (nthis > kWave * W) { no_list(0); return; }                 // (W waves of k_pair_list share the cell: up to 64 atoms each)
     const int RECB = L.entryScale;                                  // record number -> list entry (k_pair_list's mode decides: byte offset or number)
     const int candLds = L.candLds;
     const float hf0 = (float)(0.5 * P.csz[0]), hf1 = (float)(0.5 * P.csz[1]), hf2 = (float)(0.5 * P.csz[2]);
@@ -489,7 +509,8 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
     const double rList = sqrt(P.pruneR2);
     const double ext2 = (h0 + rList) * (h0 + rList) + (h1 + rList) * (h1 + rList) + (h2 + rList) * (h2 + rList);
     const float thrList = (float)(P.pruneR2 + 1.9073486328125e-06 * (4.0 * ext2 + P.pruneR2));       // list radius^2 + 2^-19 x a bound of the f32 error
-    const int NS = list_slices(nthis);
+    const int aw = list_atoms_per_wave(nthis, W);                   // k_pair_list: wave w serves atoms [w aw, w aw + aw), lane = (atom - w aw) * NS + slice
+    const int NS = list_slices(aw);
     const int rcpNS = 65536 / NS + 1;
     const int nBlk = (T + 15) >> 4;
     const int nW = (nBlk + 7) >> 3;
@@ -577,22 +598,27 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
     // (debug bit 65536, tests: lists hold 14 iterations only - part of a liquid's cells then keep no list and go through the clean-up launch)
     const bool usable = !tooLong && nIter <= ((P.pad0 & 65536) ? 14 : L.iterCap);
     if (usable)
-    {   // every lane of k_pair_list's layout collects ITS entries: lane = atom * NS + slice walks entries slice, slice + NS, ... of its atom; 0 = no candidate
+    {   // every lane of k_pair_list's layout collects ITS entries: lane = slot * NS + slice of wave w walks entries slice, slice + NS, ... of atom w aw + slot;
+        // 0 = no candidate
         const int slot = (lane * rcpNS) >> 16, slice = lane - slot * NS;
-        int off = 0, cnt = 0;
-        if (slot < nthis) { off = entN[slot]; cnt = entC[slot]; }
-        const uint16_t* const src = hits + off;
-        uint4* const out = (uint4*)(L.pairs + (size_t)cell * L.iterCap * kWave) + lane;
-        for (int c = 0; c * 8 < nIter; c++)
+        for (int w = 0; w < W; w++)
         {
-            uint32_t v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
+            const int atom = w * aw + slot;
+            int off = 0, cnt = 0;
+            if (slot < aw && atom < nthis) { off = entN[atom]; cnt = entC[atom]; }
+            const uint16_t* const src = hits + off;
+            uint4* const out = (uint4*)(L.pairs + ((size_t)cell * W + w) * L.iterCap * kWave) + lane;
+            for (int c = 0; c * 8 < nIter; c++)
             {
-                const int e = (c * 8 + u) * NS + slice;
-                v[u] = (e < cnt) ? (uint32_t)src[e] : 0u;
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                {
+                    const int e = (c * 8 + u) * NS + slice;
+                    v[u] = (e < cnt) ? (uint32_t)src[e] : 0u;
+                }
+                out[c * kWave] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
             }
-            out[c * kWave] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
         }
     }
     if (lane == 0)
@@ -610,10 +636,10 @@ inline void launch_build_lists(const StepParams& P, const int32_t* cellStart, hi
 {
     pair_range_default(P, R);
     if (R.n == 0) return;
-    const BuildLds G(L.candLds, L.iterLds);
+    const BuildLds G(L.candLds, L.iterLds, L.waves);
     hipLaunchKernelGGL(k_build_lists, dim3(pair_range_grid(R.n)), dim3(kWave), G.bytes(), stream, P, cellStart, R.first, R.n, L);
 }
-inline size_t build_lists_lds_bytes(const PairLists& L) { return BuildLds(L.candLds, L.iterLds).bytes(); }
+inline size_t build_lists_lds_bytes(const PairLists& L) { return BuildLds(L.candLds, L.iterLds, L.waves).bytes(); }
 
 template <int MODE, int VDW>
 inline void launch_pair_list_as(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart, double* partials,
@@ -621,10 +647,10 @@ inline void launch_pair_list_as(const StepParams& P, const SpecTable& S, const D
 {
     const size_t lds = pair_list_lds_bytes(P, L);
     if (energies)
-        hipLaunchKernelGGL((k_pair_list<MODE, VDW, true>), dim3(pair_range_grid(R.n)), dim3(kWave), lds, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
+        hipLaunchKernelGGL((k_pair_list<MODE, VDW, true>), dim3(pair_range_grid(R.n)), dim3(kWave * L.waves), lds, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
                            cnt, R.blockBase, L, N);
     else
-        hipLaunchKernelGGL((k_pair_list<MODE, VDW, false>), dim3(pair_range_grid(R.n)), dim3(kWave), lds, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
+        hipLaunchKernelGGL((k_pair_list<MODE, VDW, false>), dim3(pair_range_grid(R.n)), dim3(kWave * L.waves), lds, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
                            cnt, R.blockBase, L, N);
 }
 
@@ -637,7 +663,7 @@ inline int launch_pair_list(const StepParams& P, const SpecTable& S, const DevPo
     if (R.n == 0) return 0;
     auto list = [&]() { AZTOT_PAIR_DISPATCH(launch_pair_list_as, P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, N, energies); };
     list();
-    return pair_range_grid(R.n);
+    return pair_range_grid(R.n) * L.waves;
 }
 
 inline int launch_pair_cleanup(const StepParams& P, const SpecTable& S, const DevPot* pots, AtomArrays A, const Counts* cnt, const int32_t* cellStart,
@@ -645,7 +671,7 @@ inline int launch_pair_cleanup(const StepParams& P, const SpecTable& S, const De
 {
     pair_range_default(P, R);
     if (R.n == 0) return 0;
-    R.blockBase += pair_range_grid(R.n);
+    R.blockBase += pair_range_grid(R.n) * L.waves;
     launch_pair_tile(P, S, pots, A, cnt, cellStart, partials, maxBlocks, stream, R, L, 2, N);
     return pair_cleanup_grid(R.n);
 }

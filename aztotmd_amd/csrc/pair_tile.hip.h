@@ -387,7 +387,10 @@ struct PairLists
     int32_t candLds = 0;           // candidates the LDS tiles of k_pair_list / k_build_lists hold (>= 256, <= candCap): sized by the engine from the largest T
                                    //      seen, because LDS per wave is what bounds the occupancy of k_pair_list (7.7 KiB: 95 us, 10.8 KiB: 106 us on the 1 M-atom box)
     int32_t iterLds = 0;           // iterations the builder's LDS list buffer holds (multiple of 8, <= iterCap)
-    int32_t recBytes = 0;          // bytes per LDS record in k_pair_list: 24 {x, y, z} or 32 {x, y, z, radius}
+    int32_t waves = 1;             // waves per cell in k_pair_list (1, 2 or 4): they share ONE tile and split the cell's atoms - where a cell's candidates are
+                                   //      many and the cells few (dense systems, slab ranks), LDS per wave and wave lifetime are what bounds the kernel.
+                                   //      `pairs` then holds `waves` lists per cell ([nCell][waves][iterCap * 64])
+    int32_t recBytes = 0;          // bytes per LDS record in k_pair_list: 24 {x, y, z}
     int32_t entryScale = 0;        // list entry of record n: n * entryScale (the record's byte offset, or its number in the table-driven modes)
     const float4* rel = nullptr;   // [atoms] written by the sort: position relative to the centre of the atom's own cell (f32) + its cell's z index; what the builder stages
 };

@@ -143,8 +143,9 @@ typedef struct
                                     0 (default): automatic (about 4 % of the cut-off; cells are sized cut-off + skin when control.cell_list asks for cells
                                     of about the cut-off); > 0: this value; < 0: no skin - cells exactly as control.cell_list / split_cells
                                     (cuCellList.cu:9-34) give them, the slack is whatever the cell edge happens to overhang the cut-off */
-    int32_t waves_per_cell;      /* staging pair kernel: waves that share one cell's stencil, 1 / 2 / 4 / 8 (0, default: the engine decides - several where
-                                    cells are few or stencils wide) */
+    int32_t waves_per_cell;      /* waves that share one cell in the pair kernels (list kernel: 1 / 2 / 4, they split the cell's atoms over one LDS tile;
+                                    staging kernel: 1 / 2 / 4 / 8, they split the stencil's columns).  0 (default): the engine decides - several where
+                                    cells are few, tiles large or stencils wide */
     int32_t energies_every_step; /* 1: pair energies are booked on every step (0, default: only on the last step of an aztot_step call, the only one whose
                                     statistics the caller can see; forces and trajectories are bit-identical either way) */
     int32_t loopback_ranks;      /* measurement aid for aztot_init_device_slab without a transport: 1 = this rank exchanges its halo with itself
