@@ -1357,9 +1357,17 @@ void Engine::prepare_next_call()
         check_launch("list building");
         sync();
         {
-            int32_t nl = 0;
-            HIP_CHECK(hipMemcpy(&nl, dNoList_ + 2, sizeof(nl), hipMemcpyDeviceToHost));
-            unlistedState_ = (nl == 0) ? 1 : 2;
+            int32_t nl[8];
+            HIP_CHECK(hipMemcpy(nl, dNoList_, sizeof(nl), hipMemcpyDeviceToHost));
+            unlistedState_ = (nl[2] == 0) ? 1 : 2;
+            // the first lists of an engine's life: size the LDS tiles from what the cells really hold right away (adapt_sort_interval does the same at
+            // every look) - the next call then walks them at full occupancy
+            if (nl[5] == 0 && nl[6] == 0 && nl[3] > 0 && !(debug_ & 65536))
+            {
+                const int candLds = std::max(kWave, std::min(candCap_, (nl[3] + nl[3] / 25 + 6 + 7) & ~7));
+                const int iterLds = std::max(2 * kListMinIter, std::min(iterCap_, (nl[4] + nl[4] / 8 + 2 + 7) & ~7));
+                if (candLds < candLds_ || iterLds < iterLds_) { candLds_ = std::min(candLds_, candLds); iterLds_ = std::min(iterLds_, iterLds); destroy_graphs(); graphCycle_ = 0; }
+            }
         }
         if (nranks_ > 1)
         {   // the plain steps' coordinate exchange needs to know where the boundary layers sit; with interval 1 nobody had asked (k_rank_gather left it ready)

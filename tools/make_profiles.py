@@ -46,6 +46,7 @@ fp64_dir = os.path.join(os.path.dirname(fetch_dir.rstrip("/")), "fp64")
 flop = {}
 if os.path.isdir(fp64_dir):
     c = {n: means(fp64_dir, "SQ_INSTS_VALU_%s_F64" % n) for n in ("FMA", "ADD", "MUL", "TRANS", "MFMA_MOPS")}
+    c["MFMA_MOPS_F32"] = means(fp64_dir, "SQ_INSTS_VALU_MFMA_MOPS_F32")
     for k in set().union(*[set(v) for v in c.values()]):
         g = lambda n: c[n].get(k, (0.0, 0))[0]
         flop[k] = (2.0 * g("FMA") + g("ADD") + g("MUL") + g("TRANS")) * 64.0 + 512.0 * g("MFMA_MOPS")
@@ -61,9 +62,11 @@ for r in rows:
     # bench.py's names: k_pair_list -> pair_list ; k_pair_tile<MODE, VDW, CLEANUP, BUILD>: BUILD -> build_lists, CLEANUP -> pair_cleanup, else pair_tile
     if k.startswith("k_pair_list<"):
         name = "pair_list"
+    elif k.startswith("k_build_lists"):
+        name = "build_lists"
     elif k.startswith("k_pair_tile<"):
         a = [x.strip() for x in k[k.index("<") + 1:k.rindex(">")].split(",")]
-        name = "build_lists" if (len(a) > 3 and a[3] == "true") else ("pair_cleanup" if (len(a) > 2 and a[2] == "true") else "pair_tile")
+        name = "pair_cleanup" if (len(a) > 2 and a[2] == "true") else "pair_tile"
     else:
         name = "pair_atom" if k == "k_pair_atom" else None
     if name and r["dispatches"] > seen.get(name, 0):
