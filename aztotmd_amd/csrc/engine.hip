@@ -1364,7 +1364,7 @@ void Engine::prepare_next_call()
             // every look) - the next call then walks them at full occupancy
             if (nl[5] == 0 && nl[6] == 0 && nl[3] > 0 && !(debug_ & 65536))
             {
-                const int candLds = std::max(kWave, std::min(candCap_, (nl[3] + nl[3] / 25 + 6 + 7) & ~7));
+                const int candLds = std::max(4 * kWave, std::min(candCap_, (nl[3] + nl[3] / 25 + 6 + 7) & ~7));
                 const int iterLds = std::max(2 * kListMinIter, std::min(iterCap_, (nl[4] + nl[4] / 8 + 2 + 7) & ~7));
                 if (candLds < candLds_ || iterLds < iterLds_) { candLds_ = std::min(candLds_, candLds); iterLds_ = std::min(iterLds_, iterLds); destroy_graphs(); graphCycle_ = 0; }
             }
@@ -1418,7 +1418,7 @@ void Engine::adapt_sort_interval()
             // LDS per wave is what bounds the occupancy of k_pair_list: the tiles are sized from the largest cell ever recorded (+ 6 %), not from the
             // capacity of the arrays.  A cell that does not fit next time keeps no list for one interval (exact: the clean-up launch serves it) and is
             // counted; then the tiles grow again.
-            int candLds = std::max(kWave, std::min(candCap_, (nl[3] + nl[3] / 25 + 6 + 7) & ~7));
+            int candLds = std::max(4 * kWave, std::min(candCap_, (nl[3] + nl[3] / 25 + 6 + 7) & ~7));
             int iterLds = std::max(2 * kListMinIter, std::min(iterCap_, (nl[4] + nl[4] / 8 + 2 + 7) & ~7));
             if (nl[5] > 0) candLds = std::min(candCap_, std::max(candLds, candLds_ + 32));
             if (nl[6] > 0) iterLds = std::min(iterCap_, std::max(iterLds, iterLds_ + 8));

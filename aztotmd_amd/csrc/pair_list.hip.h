@@ -56,8 +56,10 @@ inline int pair_list_entry_scale(const StepParams& P) { return P.single_lj ? 24 
 // ENG = false: the launch books no energies (steps whose energies nobody can see: all but the last step of an aztot_step call - the statistics are those of
 // the last step, finish_steps; the reference prints them every `stat` steps, cuStat.cu:308-330).  Forces are the same instructions either way: the energy
 // terms feed nothing else, the compiler drops them and their two wave reductions.
-template <int MODE, int VDW, bool ENG>
-__global__ __launch_bounds__(kWave * kListMaxWaves) void k_pair_list(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
+// MULTI = false: one wave per cell, known when the kernel is compiled (the wave number and every multiple of W fold away: 585 -> 515 vector instructions per
+// cell on the 1 M-atom liquid); true: W = PairLists::waves waves share the cell's tile.
+template <int MODE, int VDW, bool ENG, bool MULTI>
+__global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_list(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase, PairLists L,
                                                      NextStep N)
@@ -75,8 +77,8 @@ __global__ __launch_bounds__(kWave * kListMaxWaves) void k_pair_list(StepParams 
     double* const trad = (double*)(tb + (size_t)(L.candLds + 1) * RECB);         // MODE 0 / 4: radii (by record number)
     uint8_t* const ttyp0 = (uint8_t*)(trad + (L.candLds + 1));                   // MODE 0 only: species ids (by record number)
 
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int W = L.waves;                                           // waves of this workgroup = waves per cell (they share the tile, each serves its share of the atoms)
+    const int lane = threadIdx.x & (kWave - 1), wave = MULTI ? (int)(threadIdx.x >> 6) : 0;
+    const int W = MULTI ? L.waves : 1;                               // waves of this workgroup = waves per cell (they share the tile, each serves its share of the atoms)
     const int per = (nCellsRun + 7) >> 3;
     const int cr = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware: each XCD owns a contiguous eighth of the cells
     double eV = 0.0, eC = 0.0, dropped = 0.0, eK = 0.0;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(kWave * kListMaxWaves) void k_pair_list(StepParams 
             };
             auto put = [&](int u, uint32_t e, const Cand& c) {
                 // (the tile holds candLds records, not whole groups of 64: LDS per wave bounds the occupancy; the first four groups always fit)
-                if (u * kWave + lane >= L.candLds) return;
+                if ((MULTI || u >= 4) && u * kWave + lane >= L.candLds) return;      // (one wave: its first four groups always fit, candLds >= 256)
                 double xj = c.x, yj = c.y, zj = c.z;
                 if (images)
                 {   // image code per axis: 0 -> -L, 1 -> 0, 2 -> +L (exact: the product is +-L or 0)
@@ -646,12 +648,11 @@ inline void launch_pair_list_as(const StepParams& P, const SpecTable& S, const D
                                 int maxBlocks, hipStream_t stream, PairRange R, PairLists L, NextStep N, bool energies)
 {
     const size_t lds = pair_list_lds_bytes(P, L);
-    if (energies)
-        hipLaunchKernelGGL((k_pair_list<MODE, VDW, true>), dim3(pair_range_grid(R.n)), dim3(kWave * L.waves), lds, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
-                           cnt, R.blockBase, L, N);
-    else
-        hipLaunchKernelGGL((k_pair_list<MODE, VDW, false>), dim3(pair_range_grid(R.n)), dim3(kWave * L.waves), lds, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks,
-                           cnt, R.blockBase, L, N);
+    const dim3 grid(pair_range_grid(R.n)), block(kWave * L.waves);
+#define AZTOT_LAUNCH_LIST(E, M) hipLaunchKernelGGL((k_pair_list<MODE, VDW, E, M>), grid, block, lds, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt, R.blockBase, L, N)
+    if (L.waves == 1) { if (energies) AZTOT_LAUNCH_LIST(true, false); else AZTOT_LAUNCH_LIST(false, false); }
+    else { if (energies) AZTOT_LAUNCH_LIST(true, true); else AZTOT_LAUNCH_LIST(false, true); }
+#undef AZTOT_LAUNCH_LIST
 }
 
 // a plain step: the list kernel for every cell (launch_pair_list), then the clean-up launch of the staging kernel for the cells that keep no list
