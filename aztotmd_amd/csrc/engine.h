@@ -34,6 +34,9 @@ namespace aztot {
 // results unchanged (up to summation order): they select between code paths for A/B timing and let the tests reach paths a normal run rarely takes.
 enum DebugBit : unsigned
 {
+    DBG_BUILD_PHASE_MASK = 3,            // NOT result-preserving (phase timing of k_build_lists): 1 staging only, 2 + candidates and filter, 3 + compaction
+    DBG_LDS_FAKE_TILE = 4,               // NOT result-preserving (LDS experiment, one-species LJ list kernel): every candidate in a small cluster above the cell, forces not stored
+    DBG_LDS_NO_CONFLICTS = 8,            // NOT result-preserving (with 4): list entries replaced by 32 distinct bank pairs per half wave
     DBG_KICK_EVERY_STEP = 128,           // k_integrate2 launched every step
     DBG_LARGE_KICK_PATH = 256,           // the deferred half-kick of large systems whatever the size
     DBG_GENERIC_PAIR = 512,              // the generic (switch-based) pair body instead of a specialised mode

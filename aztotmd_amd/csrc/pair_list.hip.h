@@ -173,6 +173,11 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
                 }
                 char* const r = tb + (size_t)(u * kWave + lane + 1) * RECB;       // candidate k -> record k + 1 (record 0 is the dummy)
                 *(double*)r = xj - cc0; *(double*)(r + 8) = yj - cc1; *(double*)(r + 16) = zj - cc2;
+                if (MODE == 1 && (P.pad0 & 4))
+                {   // (LDS experiment, timing only: every candidate sits in a small cluster above the cell, within reach of all its atoms)
+                    const int n = u * kWave + lane;
+                    *(double*)r = 0.1 * (n % 7) - 0.3; *(double*)(r + 8) = 0.1 * ((n / 7) % 7) - 0.3; *(double*)(r + 16) = 6.4 + 0.01 * (n % 11);
+                }
                 if (kTab) ttypT[u * kWave + lane + 1] = (uint8_t)c.typ;
                 if (kRadii) trad[u * kWave + lane + 1] = c.rad;
                 if (MODE == 0) ttyp0[u * kWave + lane + 1] = (uint8_t)c.typ;
@@ -242,7 +247,8 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
             {
                 const int t = c * 8 + u;
                 if (t >= nIter) break;                                  // wave-uniform
-                const uint32_t kn = ((u + 1) & 1) ? (ww[(u + 1) >> 1] >> 16) : (ww[(u + 1) >> 1] & 0xFFFFu);      // byte offset of the next candidate's record
+                uint32_t kn = ((u + 1) & 1) ? (ww[(u + 1) >> 1] >> 16) : (ww[(u + 1) >> 1] & 0xFFFFu);      // byte offset of the next candidate's record
+                if (MODE == 1 && (P.pad0 & 8)) kn = (uint32_t)((((lane + 4 * t) & 31) + 1 + 32 * ((t >> 3) & 7)) * 24);       // (LDS experiment: 32 distinct bank pairs per half wave)
                 double xn, yn, zn, radn = 0.0;
                 int tn = 0;
                 fetch(kn, xn, yn, zn, tn, radn);
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
             const double fxi = -q * P.E[0] + acc.fx;   // clear_force integrators.cpp:17-39
             const double fyi = -q * P.E[1] + acc.fy;
             const double fzi = -q * P.E[2] + acc.fz;
-            A.fx[myi] = fxi; A.fy[myi] = fyi; A.fz[myi] = fzi;
+            if (!(MODE == 1 && (P.pad0 & 12))) { A.fx[myi] = fxi; A.fy[myi] = fyi; A.fz[myi] = fzi; }
             if (P.fuseKick || N.xn)
             {   // second half-kick + kinetic energy of integrate2 (integrators.cpp:486-531 ; verlet_2stage cuMDfunc.cu:521-600); with NextStep also the
                 // next step's k_integrate1_bin<2>

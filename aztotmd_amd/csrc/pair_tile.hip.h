@@ -825,6 +825,12 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 
         }
         if (nSplit > 1)
         {
+            // Hand-off without fences (a release / acquire pair at agent scope makes gfx950 write the whole L2 back: 40 us per wave, measured).  Why the weaker
+            // form is safe HERE: the partial forces are agent-scope atomic stores (they go to the level all CUs see, not to a CU-private cache); a wave issues
+            // in order and s_waitcnt vmcnt(0) holds it until every one of those stores has been acknowledged by that level, so the arrival count cannot
+            // go up before they are visible; the last arriver reads them back with agent-scope atomic loads, which do not hit in its own non-coherent caches.
+            // The compiler cannot move the stores past the asm (memory clobber) nor the loads above the atomic's result they depend on (control dependence
+            // through `before`).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial forces above have reached the coherent level before the count goes up
             int before = 0;
             if (lane == 0) before = atomicAdd(&Z.arrived[cell], 1);
