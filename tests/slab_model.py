@@ -111,6 +111,16 @@ def main():
         ghosts = np.concatenate([ghosts_from(fl, fr), mig_left, mig_right]).astype(int)    # emigrants are kept as ghosts
         owned = np.concatenate([stay, np.array(arrivals, dtype=int)]).astype(int)
         assert len(set(owned) & set(ghosts)) == 0 and len(set(ghosts)) == len(ghosts)
+        # The invariant the device engine checks before the plain steps of a lazy run post their coordinate exchange (Engine::adopt_halo_info; the counts travel
+        # in fixed-size messages, Exchanger::exchange_counts): what a rank will send to a neighbour - its outermost hw owned layers as they are AFTER the
+        # migration - is exactly what that neighbour holds as ghosts on that side (halo it received + its own emigrants, kept as ghosts).  Both ranks of
+        # a boundary see both numbers.
+        lay_now = layer(P[owned, 0])
+        send_left, send_right = int(np.sum((lay_now - lo) % ncx < hw)), int(np.sum((lay_now - lo) % ncx >= (hi - lo) - hw))
+        ghosts_left, ghosts_right = len(fl["halo"]) + len(mig_left), len(fr["halo"]) + len(mig_right)
+        cl, cr = exchange(rank, world, (send_left, ghosts_left), (send_right, ghosts_right))
+        # cl = the left neighbour's (what it sends rightward, its right ghosts) ; cr = the right neighbour's (what it sends leftward, its left ghosts)
+        assert cr[0] == ghosts_right and cr[1] == send_right and cl[0] == ghosts_left and cl[1] == send_left, (rank, cl, cr, send_left, ghosts_left, send_right, ghosts_right)
         F[owned] = forces_for(case, owned, ghosts, P, types)
         V[owned] += (0.5 * dt / mass[owned])[:, None] * F[owned]
     # gather and compare with the single-domain oracle
@@ -128,7 +138,7 @@ def main():
         s = ref.state()
         err = {k: float(np.abs(a - np.stack([s[k + c] for c in "xyz"], 1) if k else a - np.stack([s[c] for c in "xyz"], 1)).max())
                for k, a in (("", Pm), ("v", Vm), ("f", Fm))}
-        print("SLAB_MODEL " + json.dumps({"world": world, "err": err, "fmax": float(np.abs(Fm).max())}))
+        print("SLAB_MODEL " + json.dumps({"world": world, "err": err, "fmax": float(np.abs(Fm).max()), "boundary_counts_checked": nsteps}))
     dist.barrier()
     dist.destroy_process_group()
 

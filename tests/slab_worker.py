@@ -72,6 +72,8 @@ def main():
         case = random_case(int(name[4:]), x_cells=2 * world + 2)
     elif name == "big":      # long enough along x for 8 slabs of >= 2 cell layers
         case = inputs.lj_case((40, 5, 5), a=5.26, seed=13, rc=6.5, cell_list=6.5, vel_T=600.0)
+    elif name == "heat":     # cold start (long sort interval), then the velocities are tripled between two calls
+        case = inputs.lj_case((16, 6, 6), a=5.26, seed=6, vel_T=60.0)
     elif name == "hot":
         case = inputs.lj_case((14, 5, 5), a=5.4, seed=3, rc=7.0, cell_list=7.0, vel_T=4000.0)
     else:
@@ -99,7 +101,16 @@ def main():
         cp.barrier()
         cp.close()
         return
+    def heat(e):
+        # a heating protocol between two calls: velocities x 3 through aztot_set_state.  The sort interval measured on the slow atoms must not be carried
+        # over (a slab rank cannot repair a skin violation, only report it): set_state forgets it, every step rebuilds until the next look
+        sv = e.state(("vx", "vy", "vz"))
+        e.set_state(**{k: np.nan_to_num(sv[k], nan=0.0) * 3.0 for k in ("vx", "vy", "vz")})
+
     eng.step(first)                      # two calls: the second one runs on the sort interval the first one measured
+    if name == "heat":
+        assert eng.stats()["sort_interval"] > 1
+        heat(eng)
     eng.step(nsteps - first)
     st = eng.stats()
     spec_cross = eng.species_crossings()
@@ -114,6 +125,8 @@ def main():
     if rank == 0:
         ref = api.Engine(api.Model.from_case(case), device=dev, **extra)
         ref.step(first)
+        if name == "heat":
+            heat(ref)
         ref.step(nsteps - first)
         rs, rst = ref.state(), ref.stats()
         from util import rel_err

@@ -76,6 +76,14 @@ def test_slabs_on_random_dynamics(seed, nranks):
     assert all(v < 1e-8 for v in out["energy_rel"].values()), out["energy_rel"]
 
 
+def test_slabs_survive_a_heating_step_between_two_calls():
+    """aztot_set_state with faster velocities between two aztot_step calls (a heating protocol, a restart): the interval measured on the slow atoms is
+    forgotten (every step rebuilds until the next look), so the slab ranks - which cannot repair a skin violation, only report it - stay exact."""
+    out = run_ranks(2, "heat", 45, port=29623)
+    assert out["every_atom_owned_once"] and out["max_rel_err_vs_single"] < 1e-9, out["errs"]
+    assert all(v < 1e-10 for v in out["energy_rel"].values()), out["energy_rel"]
+
+
 def test_slabs_with_deferred_half_kick():
     """debug bit 256: the large-system path (second half-kick applied by the next step's k_integrate1_bin, which in slab mode also
     packs the migrants and the halo from the freshly kicked velocities)."""

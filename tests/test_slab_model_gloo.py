@@ -19,5 +19,5 @@ def test_slab_protocol_model_matches_single_domain(world, port):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("SLAB_MODEL ")]
     assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-2000:])
     out = json.loads(lines[-1][len("SLAB_MODEL "):])
-    assert out["world"] == world
+    assert out["world"] == world and out["boundary_counts_checked"] == 12      # every step: senders' and receivers' boundary counts agree on both sides
     assert out["err"][""] < 1e-11 and out["err"]["v"] < 1e-10 and out["err"]["f"] < 1e-11 * max(out["fmax"], 1.0), out
