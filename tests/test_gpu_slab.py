@@ -21,10 +21,11 @@ def transport_for(nranks):
     return "rccl" if api.device_count() >= nranks else "callback"
 
 
-def run_ranks(nranks, name, nsteps, extra=None, port=29611, transport=None):
+def run_ranks(nranks, name, nsteps, extra=None, port=29611, transport=None, env_extra=None):
     transport = transport or transport_for(nranks)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(env_extra or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "slab_worker.py"), name, str(nsteps), transport, json.dumps(extra or {})]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
@@ -82,6 +83,24 @@ def test_slabs_survive_a_heating_step_between_two_calls():
     out = run_ranks(2, "heat", 45, port=29623)
     assert out["every_atom_owned_once"] and out["max_rel_err_vs_single"] < 1e-9, out["errs"]
     assert all(v < 1e-10 for v in out["energy_rel"].values()), out["energy_rel"]
+
+
+def test_slabs_with_several_waves_per_cell():
+    """options.waves_per_cell = 2: two waves share the LDS tile of a cell in the list kernel (and two waves split the stencil's columns in the staging
+    kernel) - on slab ranks, where ghost cells are candidates but never served"""
+    out = run_ranks(2, "fennel", 30, extra={"split": 2}, port=29624)
+    assert out["every_atom_owned_once"] and out["max_rel_err_vs_single"] < 1e-9, out["errs"]
+    assert all(v < 1e-10 for v in out["energy_rel"].values()), out["energy_rel"]
+
+
+def test_slab_ranks_grow_their_lists_together():
+    """Lists that start too small (AZTOT_ITER_CAP forces 16 iterations per cell: every cell of this liquid needs more) are re-allocated at the first look;
+    the rebuild that must follow is agreed between the ranks (a rebuild step carries the full exchange: one rank rebuilding alone would desynchronise the
+    protocol), and the run stays equal to the single-rank engine's."""
+    out = run_ranks(3, "lj", 60, port=29625, env_extra={"AZTOT_ITER_CAP": "16", "AZTOT_VERBOSE": "1"})
+    assert out["every_atom_owned_once"] and out["max_rel_err_vs_single"] < 1e-9, out["errs"]
+    assert all(v < 1e-10 for v in out["energy_rel"].values()), out["energy_rel"]
+    assert out["sort_interval"] > 1 and out["pair_lists"] == 1 and out["cells_without_list"] == 0, out
 
 
 def test_slabs_with_deferred_half_kick():
