@@ -364,11 +364,9 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
     extern __shared__ float ldsBuild[];
     const int W = L.waves;
     const BuildLds G(L.candLds, L.iterLds, W);
-    float* const tx = ldsBuild;
-    float* const ty = tx + G.capS;
-    float* const tz = ty + G.capS;
-    float* const tw = tz + G.capS;                                  // -(x^2 + y^2 + z^2): the C operand of the filter
-    uint32_t* const tent = (uint32_t*)(tw + G.capS);                // list entries of the candidates (atom index | image code << 26), tile order ...
+    float4* const tile = (float4*)ldsBuild;                         // {x, y, z, -(x^2 + y^2 + z^2)} of every candidate, relative to the cell centre: one 16-byte store each;
+                                                                    // lane (row c, component k) of the matrix operand reads float 4 (16 b + perm(c)) + k: 64 different banks
+    uint32_t* const tent = (uint32_t*)(tile + G.capS);              // list entries of the candidates (atom index | image code << 26), tile order ...
     uint16_t* const hits = (uint16_t*)tent;                         // ... and, once those have left, the compact hit array (entries of k_pair_list's lists, atom by atom)
     uint32_t* const maskBuf = (uint32_t*)((char*)tent + G.union_bytes());      // [nWords][64] hit masks of the atom group in flight
     int32_t* const entJ = (int32_t*)(maskBuf + (size_t)G.nWords * kWave);      // staging table: first atom, count (<= 64), codes ; later, per atom of the cell:
@@ -478,8 +476,7 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
                             if (keep)
                             {
                                 const int pp = T + lanes_below(mask);
-                                tx[pp] = xf; ty[pp] = yf; tz[pp] = zf;
-                                tw[pp] = -(xf * xf + yf * yf + zf * zf);
+                                tile[pp] = make_float4(xf, yf, zf, -(xf * xf + yf * yf + zf * zf));
                                 tent[pp] = (uint32_t)(__builtin_amdgcn_readlane(vj, u) + lane) | ((uint32_t)(code & 63) << 26);
                             }
                             T += nk;
@@ -500,7 +497,7 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
         for (int q = lane; q < Tpad; q += kWave) myList[q] = (q < T) ? tent[q] : ((uint32_t)ib | (0x15u << 26));
     }
     // far-away, finite dummies behind the last candidate up to the end of its mask word: the filter reads whole words of 8 x 16 candidates, without guards
-    for (int q = T + lane; q < ((T + 127) & ~127); q += kWave) { tx[q] = -1e30f; ty[q] = 0.0f; tz[q] = 0.0f; tw[q] = -3e38f; }
+    for (int q = T + lane; q < ((T + 127) & ~127); q += kWave) tile[q] = make_float4(-1e18f, 0.0f, 0.0f, -3e38f);
     // where the cell's own atoms sit in the tile (they are candidates too, unshifted): found by their list entries
     for (int q = lane; q < T; q += kWave)
     {
@@ -524,8 +521,9 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
     const int nW = (nBlk + 7) >> 3;
     const int c16 = lane & 15, kq = lane >> 4;
     const int permc = (c16 >> 2) + ((c16 & 3) << 2);
-    const float* const pa = (kq == 0 ? tx : kq == 1 ? ty : kq == 2 ? tz : tx) + permc;       // (lanes kq = 3 feed the constant 1: what they read is ignored)
-    const float* const pc = tw + kq;
+    // A[cand][k] = (xj, yj, zj, -|rj|^2), B[k][atom] = (2 xi, 2 yi, 2 zi, 1), C[cand][atom] = thr - |ri|^2 (the same in a lane's four registers, for every block):
+    // the per-candidate term rides in the A operand, so a block costs ONE LDS read per lane and no operand selects
+    const float* const pa = (const float*)tile + 4 * permc + kq;
     int nIter = 0, hitBase = 0, tooLong = 0;
     for (int g0 = 0; g0 < nthis; g0 += 16)
     {
@@ -534,7 +532,9 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
         // idle atom slots sit at 1e18: their column of the filter is hugely negative ("outside") whatever the candidate
         float4 me = make_float4(1e18f, 1e18f, 1e18f, 0.f);
         if (validA) me = L.rel[ib + a];
-        const float fB = (kq == 0) ? 2.0f * me.x : (kq == 1) ? 2.0f * me.y : (kq == 2) ? 2.0f * me.z : thrList - (me.x * me.x + me.y * me.y + me.z * me.z);
+        const float fB = (kq == 0) ? 2.0f * me.x : (kq == 1) ? 2.0f * me.y : (kq == 2) ? 2.0f * me.z : 1.0f;
+        const float cAtom = thrList - (me.x * me.x + me.y * me.y + me.z * me.z);
+        const float4_t cw = {cAtom, cAtom, cAtom, cAtom};
         const int kSelf = validA ? entJ[a] : -1;
         int h = 0;
         for (int wd = 0; wd < nW; wd++)
@@ -542,19 +542,13 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
             // all operands of the word's eight blocks first (the tile is padded with dummies to the end of the word), then the eight matrix instructions,
             // then the sign bits: no guards, so the reads of one block do not wait for the arithmetic of the one before
             float av[8];
-            float4_t cw[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++)
-            {
-                const int o = (8 * wd + q) * 16;
-                av[q] = pa[o];
-                cw[q] = float4_t{pc[o], pc[o + 4], pc[o + 8], pc[o + 12]};
-            }
+            for (int q = 0; q < 8; q++) av[q] = pa[(8 * wd + q) * 64];
             uint32_t miss = 0u;                                      // one bit per candidate of the lane, 1 = outside; newest candidate in bit 0
 #pragma unroll
             for (int q = 0; q < 8; q++)
             {
-                const float4_t d = __builtin_amdgcn_mfma_f32_16x16x4f32((kq == 3) ? 1.0f : av[q], fB, cw[q], 0, 0, 0);
+                const float4_t d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], fB, cw, 0, 0, 0);
                 miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[0]), 31);
                 miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[1]), 31);
                 miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(d[2]), 31);
