@@ -1423,6 +1423,27 @@ void Engine::adapt_sort_interval()
             if (nl[5] > 0) candLds = std::min(candCap_, std::max(candLds, candLds_ + 32));
             if (nl[6] > 0) iterLds = std::min(iterCap_, std::max(iterLds, iterLds_ + 8));
             if (debug_ & 65536) { candLds = candLds_; iterLds = iterLds_; }
+            // more waves per cell where the cells turn out denser than the mean density promised (a droplet in a large box - case study 2: tiles of 1 487
+            // candidates, lists of 210 iterations where the homogeneous estimate said 1 wave would do): decided from what the builder recorded
+            {
+                const double tileNow = (double)nl[3] * (P_.single_lj ? 24.0 : (pair_list_tab_mode(P_) ? 25.0 : 32.0));
+                int wWant = listWaves_;
+                if (tileNow > 13.0 * 1024 || nl[4] > 96) wWant = std::max(wWant, 2);
+                if (tileNow > 26.0 * 1024 || nl[4] > 192) wWant = 4;
+                const bool forced = opt_.waves_per_cell == 1 || opt_.waves_per_cell == 2 || opt_.waves_per_cell == 4;
+                if (wWant > listWaves_ && !forced && !(debug_ & 65536))
+                {
+                    const int itersNew = std::max(2 * kListMinIter, ((int)(nl[4] * (double)listWaves_ / wWant * 1.3) + 8 + 7) & ~7);
+                    const int candNew = std::max(candCap_, kListMinCand * wWant);
+                    listWaves_ = wWant;
+                    destroy_graphs(); graphCycle_ = 0;
+                    allocate_lists(candNew, itersNew);
+                    rebuildNeeded = true;
+                    nl[1] = 0;                                  // (what was recorded describes lists that no longer exist: nothing more to decide now)
+                }
+            }
+            if (nl[1] > 0)
+            {
             const bool capFull = (nl[5] > 0 && candLds_ == candCap_) || (nl[6] > 0 && iterLds_ == iterCap_);
             if (capFull && !(debug_ & 65536) && (double)(nl[5] + nl[6]) > 0.0005 * (double)nl[1])
             {   // the arrays themselves are too small: larger ones if the limits allow (twice), and the next step rebuilds; else - cells of more than 64 atoms
@@ -1440,6 +1461,7 @@ void Engine::adapt_sort_interval()
             if (listsOn_ && (double)nl[0] > 0.02 * (double)nl[1] && !(debug_ & 65536) && nl[5] + nl[6] < nl[0] / 2)
             {   // mostly cells of more than 64 atoms: no list will ever hold them
                 listsOn_ = false; listsValid_ = false; destroy_graphs(); graphCycle_ = 0;
+            }
             }
         }
     }

@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C4", help="C4 (1 000 188 Ar LJ, default), C4T (the same at 85 K), C4X, C3 / C3T (+Fennell Coulomb), C2 / C2T (40 000 Ar LJ), M4, S4, S40, B3, E2")
+    ap.add_argument("--case-study", type=int, default=0, help="1 or 2: run the reference's shipped example input verbatim (BASELINE configs 1 and 5; atoms.xyz / field.txt / control.txt / "
+                                                              "cuda.txt written back from tests/golden/case_study_K.npz and parsed by aztot_init_md) instead of a synthetic workload")
     ap.add_argument("--pair-variant", type=int, default=0)
     ap.add_argument("--cell-size", type=float, default=0.0)
     ap.add_argument("--sort-every", type=int, default=0, help="cell-list rebuild schedule: 0 adaptive lazy re-sort (default), 1 every step (the reference's), n at most every n-th step")
@@ -141,9 +143,22 @@ def main():
     oversubscribed = world > ndev          # rehearsal on a box with fewer GPUs than ranks: ranks share devices, RCCL cannot be used
     dev = local_rank % ndev
 
-    case = inputs.config(a.workload)
-    n_atoms = len(case["types"])
-    model = api.Model.from_case(case)
+    if a.case_study in (1, 2):
+        # the reference's own input surface: four text files in a directory, parsed by the library (sys_init.cpp:1036-1119)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from util import materialise_case_study
+        td = tempfile.mkdtemp(prefix="aztot_cs%d_" % a.case_study)
+        materialise_case_study(a.case_study, td)
+        model = api.Model.from_dir(td)
+        n_atoms = int(model.query("n_atoms")[0])
+        case = {"dt": float(model.query("dt")[0]), "types": [0] * n_atoms, "tstat_type": 2}
+        a.workload = "case study %d" % a.case_study
+        WORKLOADS[a.workload] = "the reference's shipped 'case study %d' input, verbatim (%d atoms)" % (a.case_study, n_atoms)
+        a.no_cpu_baseline = True
+    else:
+        case = inputs.config(a.workload)
+        n_atoms = len(case["types"])
+        model = api.Model.from_case(case)
     slab = None
     if world > 1:
         idb = cp.broadcast(api.rccl_unique_id() if rank == 0 else None)
