@@ -138,6 +138,7 @@ private:
     char* dMsg_[4] = {nullptr, nullptr, nullptr, nullptr};   // sendLeft, sendRight, fromLeft, fromRight
     MsgLayout lay_{};
     int pairBlocks_ = 0, pairBlocksUsed_ = 0, splitBlocks_ = 0;
+    int blocksEver_ = 0;            // partial-sum entries any launch has booked into so far (what k_collect has to read of the accumulating rows)
     // lazy re-sort (one GPU): the cells are rebuilt only every lazyK_ steps; in between the atoms keep their slots, coordinates stay unwrapped and
     // every step checks that no atom has moved farther than lazySlack_ from where it was sorted (RefPos) - see Engine::step
     bool lazyOn_ = false;

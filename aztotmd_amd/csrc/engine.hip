@@ -945,6 +945,7 @@ void Engine::launch_pair()
         });
     if (variant < 2) fuseNow_ = false;           // only the tile kernels have the fused epilogue (cannot happen: see the constructor)
     pairBlocksUsed_ = (variant == 3) ? pair_quad_grid(P_) : (variant == 2) ? (splitBlocks_ ? splitBlocks_ : pair_tile_grid(P_) * split_.n) : div_up(capacity_, kBlock);
+    blocksEver_ = std::max(blocksEver_, std::max(pairBlocksUsed_, div_up(capacity_, kBlock)) + 1);
 }
 
 // slab ranks: where the boundary layers sit in the sorted arrays, as read back behind the last sort
@@ -1113,7 +1114,7 @@ void Engine::collect_and_finalize(unsigned slotMask)
 {
     timed("collect", [&] {
         hipLaunchKernelGGL(k_collect, dim3(PS_COUNT * kCollectParts), dim3(256), 0, stream_, dPartials_, maxBlocks_, div_up(capacity_, kBlock), pairBlocksUsed_,
-                           dStage_, slotMask, ekinFromPair_ ? 1 : 0);
+                           dStage_, slotMask, ekinFromPair_ ? 1 : 0, blocksEver_);
     });
     timed("finalize", [&] { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, stream_, P_, dStats_, dStage_, slotMask); });
 }

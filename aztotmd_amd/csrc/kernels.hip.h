@@ -1193,16 +1193,17 @@ __global__ __launch_bounds__(kBlock) void k_boundary_radi(StepParams P, SpecTabl
 constexpr int kCollectParts = 16;
 
 __global__ __launch_bounds__(256) void k_collect(double* __restrict__ partials, int maxBlocks, int nBlocksAtoms, int nBlocksPair,
-                                                 double* __restrict__ stage, unsigned slotMask, int ekinFromPair)
+                                                 double* __restrict__ stage, unsigned slotMask, int ekinFromPair, int nBlocksEver)
 {
     __shared__ double scratch[4];
     const int slot = blockIdx.x / kCollectParts, part = blockIdx.x % kCollectParts;
     double v = 0.0;
     if ((slotMask >> slot) & 1u)
     {
-        // the accumulating slots (wall counters, dropped pairs) are read over the whole row: the pair kernels' launch layout may have changed
-        // since a drop was booked (split launches of a slab rank), and idle entries hold zeros
-        const int nb = slot_accumulates(slot) ? maxBlocks
+        // the accumulating slots (wall counters, dropped pairs) are read over every entry any launch has ever booked into (nBlocksEver: the rows are sized for
+        // four waves per cell, most engines use a quarter of that): the pair kernels' launch layout may have changed since a drop was booked (split
+        // launches of a slab rank, more waves per cell), and idle entries hold zeros
+        const int nb = slot_accumulates(slot) ? min(maxBlocks, nBlocksEver)
                        : ((slot == PS_EVDW || slot == PS_ECOUL || (slot == PS_EKIN && ekinFromPair)) ? nBlocksPair : nBlocksAtoms);
         const int per = (nb + kCollectParts - 1) / kCollectParts;
         const int b0 = part * per, b1 = min(nb, b0 + per);
