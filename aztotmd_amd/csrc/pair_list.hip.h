@@ -248,6 +248,7 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
                 const int t = c * 8 + u;
                 if (t >= nIter) break;                                  // wave-uniform
                 uint32_t kn = ((u + 1) & 1) ? (ww[(u + 1) >> 1] >> 16) : (ww[(u + 1) >> 1] & 0xFFFFu);      // byte offset of the next candidate's record
+                if (u == 7 && c + 1 >= nChunks) kn = dummyOff;           // (behind the list's last chunk there is nothing the builder wrote: stale entries of an older, larger tile)
                 if (MODE == 1 && (P.pad0 & 8)) kn = (uint32_t)((((lane + 4 * t) & 31) + 1 + 32 * ((t >> 3) & 7)) * 24);       // (LDS experiment: 32 distinct bank pairs per half wave)
                 double xn, yn, zn, radn = 0.0;
                 int tn = 0;
