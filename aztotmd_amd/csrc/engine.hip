@@ -1224,19 +1224,28 @@ void Engine::finish_steps()
 void Engine::step(int nsteps)
 {
     if (nsteps <= 0) return;
-    // the sort interval is re-evaluated inside a long call after 8, 16, 32, ... steps and then every 256 (a run that starts from rest speeds up for
-    // a while: the looks are close together where that happens), and at the end of every call: a stream synchronisation and a 48-byte read-back
+    // The sort interval is re-evaluated ("a look": a stream synchronisation and a few small read-backs, ~0.1 ms with the pipeline refill) at the end of every
+    // call and, inside long calls, whenever lazyWindow_ steps have gone by since the last look - 8, 16, 32, ... then every 256 (a run that starts from rest speeds
+    // up for a while: the looks are close together where that happens).  The count runs on across calls (sinceLook_), and a look is skipped when the call
+    // ends within half a window anyway: a short call right behind a look - the driver's 20 steps after 5 of warm-up - pays for no look of its own.
+    const int windowCap = nranks_ > 1 ? 64 : 256;     // (slab ranks cannot repair a slack violation, only report it: they look more often)
     int left = nsteps;
     while (left > 0)
     {
-        const int n = lazyOn_ ? std::min(left, lazyWindow_) : left;
+        const int n = lazyOn_ ? std::min(left, std::max(1, lazyWindow_ - sinceLook_)) : left;
         run_steps(n);
         left -= n;
-        if (left > 0)
+        sinceLook_ += n;
+        if (left > 0 && sinceLook_ >= lazyWindow_)
         {
-            sync();
-            adapt_sort_interval();
-            lazyWindow_ = std::min(nranks_ > 1 ? 64 : 256, 2 * lazyWindow_);     // (slab ranks cannot repair a slack violation, only report it: they look more often)
+            if (2 * left > lazyWindow_)
+            {
+                sync();
+                adapt_sort_interval();
+                sinceLook_ = 0;
+                lazyWindow_ = std::min(windowCap, 2 * lazyWindow_);
+            }
+            else { run_steps(left); sinceLook_ += left; left = 0; }      // the end of the call, at most half a window away, is the look
         }
     }
     kickOwed_ = lazyKick_;          // set here, not in launch_step_kernels: a replayed graph does not pass through the host code
@@ -1244,7 +1253,12 @@ void Engine::step(int nsteps)
     check_launch("step kernels");
     sync();
     check_overflow();
-    if (lazyOn_) adapt_sort_interval();
+    if (lazyOn_)
+    {
+        adapt_sort_interval();
+        if (2 * sinceLook_ >= lazyWindow_) lazyWindow_ = std::min(windowCap, 2 * lazyWindow_);      // (this look stands in for the one that was due)
+        sinceLook_ = 0;
+    }
     prepare_next_call();
 }
 
@@ -1485,7 +1499,7 @@ void Engine::adapt_sort_interval()
         {
             const int32_t z = 0;
             HIP_CHECK(hipMemcpy(&dCounts_->lazyViolatedEver, &z, sizeof(z), hipMemcpyHostToDevice));
-            lazyK_ = 1; lazyMeasured_ = false; lazyWindow_ = 8; lazyViolations_++;
+            lazyK_ = 1; lazyMeasured_ = false; lazyWindow_ = 8; sinceLook_ = 0; lazyViolations_++;
             throw std::runtime_error("lazy re-sort on slab ranks: an atom left its cell's slack between two sorts (the speeds grew more than fourfold within one "
                                      "interval); the forces of this call are not exact - restart from the last state with options.sort_every = 1");
         }
@@ -1705,7 +1719,7 @@ void Engine::set_state(const aztot_state& in)
     if (in.vx || in.vy || in.vz || in.fx || in.fy || in.fz)
     {   // new velocities / forces: the interval measured on the old ones says nothing about them - every step rebuilds until the first look
         if (lazyK_ != 1 && !(debug_ & 8192)) { lazyK_ = 1; destroy_graphs(); graphCycle_ = 0; }
-        lazyMeasured_ = false; lazyWindow_ = 8;
+        lazyMeasured_ = false; lazyWindow_ = 8; sinceLook_ = 0;
     }
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
