@@ -546,9 +546,14 @@ void Engine::allocate()
                 }
                 cand = std::max(kListMinCand * listWaves_, (cand + 63) & ~63);
                 iters = std::max(2 * kListMinIter, (iters + 7) & ~7);
-                if (const char* e = std::getenv("AZTOT_CAND_CAP")) cand = std::atoi(e);        // (experiments)
+                if (const char* e = std::getenv("AZTOT_CAND_CAP")) cand = std::atoi(e);        // (experiments / tests: start from other capacities)
                 if (const char* e = std::getenv("AZTOT_ITER_CAP")) iters = std::atoi(e);
-                allocate_lists(cand, iters);
+                try { allocate_lists(cand, iters); }
+                catch (const std::exception&)
+                {   // (no room for the lists - hundreds of millions of cells: the run goes on without them, the steps between two rebuilds stage every cell)
+                    (void)hipGetLastError();
+                    free_lists();
+                }
             }
         }
     }
@@ -574,8 +579,9 @@ void Engine::allocate()
 void Engine::allocate_lists(int candCap, int iterCap)
 {
     free_lists();
-    candCap = std::min(candCap, kListCandMax);
-    iterCap = std::min(iterCap, kListIterMax);
+    // (k_pair_list asks for five groups of candidate entries per wave and two chunks of 8 iterations before it knows the cell: the arrays are never smaller)
+    candCap = std::max(kListMinCand * listWaves_, std::min((candCap + 63) & ~63, kListCandMax));
+    iterCap = std::max(kListMinIter, std::min((iterCap + 7) & ~7, kListIterMax));
     PairLists probe;
     probe.candCap = probe.candLds = candCap; probe.iterCap = probe.iterLds = iterCap; probe.recBytes = pair_list_rec_bytes(P_); probe.waves = listWaves_;
     while (candCap > kListMinCand && (pair_list_lds_bytes(P_, probe) > listLdsMax_ || build_lists_lds_bytes(probe) > listLdsMax_))
