@@ -331,6 +331,32 @@ void RcclExchanger::selftest(int device)
     HIP_CHECK(hipStreamSynchronize(st));
     double hs[3] = {0.5, -2.0, 1e300};
     x.allreduce_sum(hs, 3, st);
+    // the two exchanges of a lazy run's plain steps, with themselves as both neighbours: the fixed-size count messages and the coordinate ranges
+    // (three arrays, different counts leftward and rightward) - same grouped ncclSend / ncclRecv calls as between real ranks
+    int32_t hc[8] = {11, 22, 33, 44, 0, 0, 0, 0}, hcBack[8];
+    int32_t* dc;
+    HIP_CHECK(hipMalloc((void**)&dc, sizeof(hc)));
+    HIP_CHECK(hipMemcpyAsync(dc, hc, sizeof(hc), hipMemcpyHostToDevice, st));
+    x.exchange_counts(0, 0, dc, dc + 2, dc + 6, dc + 4, 2, st);          // to left {11, 22}, to right {33, 44}; from right -> [4..5], from left -> [6..7]
+    HIP_CHECK(hipMemcpyAsync(hcBack, dc, sizeof(hc), hipMemcpyDeviceToHost, st));
+    const int nR = 64;
+    std::vector<double> ha(3 * nR), haBack(3 * nR);
+    for (int i = 0; i < 3 * nR; i++) ha[i] = 1000.0 * (i / nR) + (i % nR);
+    double* da;
+    HIP_CHECK(hipMalloc((void**)&da, sizeof(double) * 3 * nR));
+    HIP_CHECK(hipMemcpyAsync(da, ha.data(), sizeof(double) * 3 * nR, hipMemcpyHostToDevice, st));
+    double* arrs[3] = {da, da + nR, da + 2 * nR};
+    // layout of every array: [0, 5) left ghosts | [5, 12) goes left | ... | [40, 50) goes right | [50, 57) right ghosts: 7 elements arrive from the right, 5 from the left
+    x.exchange_ranges(0, 0, arrs, 3, 5, 7, 45, 5, 0, 5, 50, 7, st);
+    HIP_CHECK(hipMemcpyAsync(haBack.data(), da, sizeof(double) * 3 * nR, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(dc); (void)hipFree(da);
+    bool rangesOk = hcBack[4] == 11 && hcBack[5] == 22 && hcBack[6] == 33 && hcBack[7] == 44;
+    for (int k = 0; k < 3 && rangesOk; k++)
+    {
+        for (int i = 0; i < 7; i++) rangesOk = rangesOk && haBack[k * nR + 50 + i] == ha[k * nR + 5 + i];       // what went left arrived as "from the right"
+        for (int i = 0; i < 5; i++) rangesOk = rangesOk && haBack[k * nR + i] == ha[k * nR + 45 + i];           // what went right arrived as "from the left"
+    }
     for (auto p : d) (void)hipFree(p);
     (void)hipFree(dd);
     (void)hipStreamDestroy(st);
@@ -338,6 +364,7 @@ void RcclExchanger::selftest(int device)
     if (ra != a || rb != b) throw std::runtime_error("RCCL self-test: ring exchange delivered the wrong payload");
     for (int k = 0; k < 8; k++) if (back[k] != h[k]) throw std::runtime_error("RCCL self-test: device all-reduce mismatch");
     if (hs[0] != 0.5 || hs[1] != -2.0 || hs[2] != 1e300) throw std::runtime_error("RCCL self-test: host all-reduce mismatch");
+    if (!rangesOk) throw std::runtime_error("RCCL self-test: count / coordinate-range exchange delivered the wrong payload");
 }
 
 }  // namespace aztot
