@@ -955,7 +955,7 @@ def test_box_that_is_a_whole_number_of_cutoffs_still_gets_a_skin():
         assert abs(st["engTot"] - sto["engTot"]) <= 1e-10 * abs(sto["engTot"])
 
 
-@pytest.mark.parametrize("kind", ["crowded_cells", "dense_wide_stencil", "sparse_cells"])
+@pytest.mark.parametrize("kind", ["crowded_cells", "dense_wide_stencil", "sparse_cells", "four_waves_per_cell"])
 def test_pair_lists_for_any_cell_population(kind):
     """Lanes of k_pair_list are (atom, slice) with 64 / atoms slices per atom - not a power of two: cells of 17 - 21 atoms run three slices each, 22 - 32 two,
     up to 64 one, a single atom eight.  'crowded_cells': cells of 1.45 rc hold 20 - 45 atoms (NS 1 - 3, lists of ~100 iterations);
@@ -966,9 +966,12 @@ def test_pair_lists_for_any_cell_population(kind):
     elif kind == "dense_wide_stencil":
         case = inputs.lj_case((12, 12, 12), a=2.3, jitter=0.05, seed=42, rc=6.0, cell_list=2.7, vel_T=300.0)
         case["vdw"] = [(0, 0, 1, 6.0, [0.002, 1.9])]
+    elif kind == "four_waves_per_cell":
+        # options.waves_per_cell = 4 on an ordinary liquid: four waves share a cell's tile and split its 10 - 20 atoms (3 - 5 each, 12 - 21 slices per atom)
+        case = inputs.lj_case((8, 8, 8), a=5.6, seed=44, rc=7.5, cell_list=7.9, vel_T=120.0)
     else:
         case = inputs.lj_case((6, 6, 6), a=14.0, jitter=2.0, seed=43, rc=7.0, cell_list=7.0, vel_T=300.0)
-    a = engine(case, pair_variant=2)
+    a = engine(case, pair_variant=2, split=4 if kind == "four_waves_per_cell" else 0)
     b = engine(case, pair_variant=2, sort_every=1)
     o = oracle.Oracle(case)
     o.forces(1)
