@@ -599,7 +599,7 @@ void Engine::allocate_lists(int candCap, int iterCap)
     const size_t nc = (size_t)P_.nCellLocal;
     auto alloc = [&](size_t bytes) { void* p = nullptr; HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16))); return p; };
     dCandList_ = (uint32_t*)alloc(sizeof(uint32_t) * nc * candCap);
-    dListMeta_ = (int32_t*)alloc(sizeof(int32_t) * 2 * nc);
+    dListMeta_ = (int32_t*)alloc(sizeof(int32_t) * 4 * nc);
     dPairList_ = (uint16_t*)alloc(sizeof(uint16_t) * nc * (size_t)listWaves_ * (size_t)iterCap * kWave);
     dNoList_ = (int32_t*)alloc(sizeof(int32_t) * 16);
     dRel_ = (float4*)alloc(sizeof(float4) * ((size_t)capacity_ + kWave));
@@ -607,14 +607,14 @@ void Engine::allocate_lists(int candCap, int iterCap)
     candCap_ = candCap; iterCap_ = iterCap;
     candLds_ = candCap; iterLds_ = iterCap;          // (tightened once the builder has reported what the cells really hold: adapt_sort_interval)
     {   // header: -1 = no list ; second word: the cell's coordinates in the local grid (the kernels decode them with shifts)
-        std::vector<int32_t> mx(2 * nc);
+        std::vector<int32_t> mx(4 * nc, 0);
         const int ncy = P_.nc[1], ncz = P_.nc[2];
         for (size_t c = 0; c < nc; c++)
         {
             const int cz = (int)(c % ncz), cy = (int)((c / ncz) % ncy), lx = (int)(c / ((size_t)ncy * ncz));
-            mx[2 * c] = -1; mx[2 * c + 1] = lx | (cy << 10) | (cz << 20);
+            mx[4 * c] = -1; mx[4 * c + 1] = lx | (cy << 10) | (cz << 20);
         }
-        HIP_CHECK(hipMemcpyAsync(dListMeta_, mx.data(), sizeof(int32_t) * 2 * nc, hipMemcpyHostToDevice, stream_));
+        HIP_CHECK(hipMemcpyAsync(dListMeta_, mx.data(), sizeof(int32_t) * 4 * nc, hipMemcpyHostToDevice, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
     }
     HIP_CHECK(hipMemsetAsync(dCandList_, 0, sizeof(uint32_t) * nc * candCap, stream_));      // every entry is an atom index at all times
@@ -1372,6 +1372,26 @@ void Engine::run_steps(int nsteps)
 // state the engine is in (capturing executes nothing).  (2) If the cells were rebuilt by the last step but no lists were recorded (the interval was 1
 // until now: the engine had not measured the atoms' speed yet), the lists of the arrays as they stand - so that the next call opens with plain steps
 // instead of rebuilding the same cells again.
+// Records of k_pair_list's LDS tile for cells of at most maxT candidates.  LDS per wave bounds the kernel's occupancy and the hardware hands LDS out in
+// blocks of 1 280 B (gfx950: 160 KiB in 128 blocks), so the tile is the largest one that costs no more blocks than the smallest one that would do
+// (largest cell + 1 % + 1): C4's largest tile of 305 candidates gives 319 records in six blocks - 21 waves per CU by LDS - where "largest + 4 % + 6" took seven.
+static int tile_records_for(const StepParams& P, const PairLists& base, int maxT, int candCap)
+{
+    constexpr size_t kLdsBlock = 1280;
+    PairLists L = base;
+    const int need = std::max(4 * kWave, std::min(candCap, maxT + maxT / 100 + 1));
+    L.candLds = need;
+    const size_t blocks = (pair_list_lds_bytes(P, L) + kLdsBlock - 1) / kLdsBlock;
+    int best = need;
+    for (int c = need + 1; c <= candCap; c++)
+    {
+        L.candLds = c;
+        if ((pair_list_lds_bytes(P, L) + kLdsBlock - 1) / kLdsBlock > blocks) break;
+        best = c;
+    }
+    return best;
+}
+
 void Engine::prepare_next_call()
 {
     if (!lazyOn_ || !lazyMeasured_) return;
@@ -1391,7 +1411,7 @@ void Engine::prepare_next_call()
             // every look) - the next call then walks them at full occupancy
             if (nl[5] == 0 && nl[6] == 0 && nl[3] > 0 && !(debug_ & 65536))
             {
-                const int candLds = std::max(4 * kWave, std::min(candCap_, (nl[3] + nl[3] / 25 + 6 + 7) & ~7));
+                const int candLds = tile_records_for(P_, pl, nl[3], candCap_);
                 const int iterLds = std::max(2 * kListMinIter, std::min(iterCap_, (nl[4] + nl[4] / 8 + 2 + 7) & ~7));
                 if (candLds < candLds_ || iterLds < iterLds_) { candLds_ = std::min(candLds_, candLds); iterLds_ = std::min(iterLds_, iterLds); destroy_graphs(); graphCycle_ = 0; }
             }
@@ -1445,7 +1465,7 @@ void Engine::adapt_sort_interval()
             // LDS per wave is what bounds the occupancy of k_pair_list: the tiles are sized from the largest cell ever recorded (+ 6 %), not from the
             // capacity of the arrays.  A cell that does not fit next time keeps no list for one interval (exact: the clean-up launch serves it) and is
             // counted; then the tiles grow again.
-            int candLds = std::max(4 * kWave, std::min(candCap_, (nl[3] + nl[3] / 25 + 6 + 7) & ~7));
+            int candLds = tile_records_for(P_, pair_lists(), nl[3], candCap_);
             int iterLds = std::max(2 * kListMinIter, std::min(iterCap_, (nl[4] + nl[4] / 8 + 2 + 7) & ~7));
             if (nl[5] > 0) candLds = std::min(candCap_, std::max(candLds, candLds_ + 32));
             if (nl[6] > 0) iterLds = std::min(iterCap_, std::max(iterLds, iterLds_ + 8));

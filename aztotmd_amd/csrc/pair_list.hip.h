@@ -17,6 +17,7 @@
 // Forces: written once per atom, no atomics, fixed summation order => bit-reproducible.  All list sizes are per engine (PairLists::candCap / iterCap,
 // dynamic LDS), so dense systems (hundreds of partners per atom, a thousand candidates per cell) walk lists too.
 #pragma once
+#include <type_traits>
 #include "pair_tile.hip.h"
 
 namespace aztot {
@@ -28,7 +29,7 @@ constexpr int kListMaxSlices = 32;         // slices per atom (a cell of one or 
 
 constexpr int kListMaxWaves = 4;
 // a cell of n atoms served by W waves: every wave takes ceil(n / W) atoms (the last ones fewer, possibly none), each with NS = 64 / that many slices
-__host__ __device__ inline int list_atoms_per_wave(int nAtoms, int W) { return (nAtoms + W - 1) / W; }
+__host__ __device__ inline int list_atoms_per_wave(int nAtoms, int W) { return (nAtoms + W - 1) >> (W >> 1); }      // (W is 1, 2 or 4: a shift, not a division)
 __host__ __device__ inline int list_slices(int nAtomsOfWave) { const int n = kWave / (nAtomsOfWave > 0 ? nAtomsOfWave : 1); return n > kListMaxSlices ? kListMaxSlices : (n < 1 ? 1 : n); }
 
 // LDS of k_pair_list by kernel mode (LDS per wave bounds its occupancy, so every byte per candidate counts):
@@ -84,8 +85,6 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
     double eV = 0.0, eC = 0.0, dropped = 0.0, eK = 0.0;
     NextAcc nacc;                                                    // (touched only in launches that fuse the next step: no initialisation on the others)
     if (N.xn) next_acc_clear(nacc);
-    // after a slack violation (one GPU) the clean-up launch stages every cell with the wider stencil: stand down
-    const bool violated = P.nranks == 1 && slack_violated(P, counts);
     // everything that depends on the cell number only is requested at once, before anything is known about the cell (the loads stay inside the
     // arrays whatever they return): list header, five groups of candidate entries, the lane's first two list chunks.  A wave's life is then two
     // memory round trips (these, then the coordinates) and the loop
@@ -99,15 +98,20 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
     uint4 w = pl[0];
     uint4 w1 = pl[kWave];                                           // (the second chunk too: 16 iterations cover a liquid's cells, and a chunk asked for only
                                                                     //  8 iterations ahead arrives late)
-    const int2 mx = ((const int2*)L.meta)[cell];                   // {list header, cell coordinates lx | cy << 10 | cz << 20}: one scalar load, no integer divisions
+    // {list header, cell coordinates lx | cy << 10 | cz << 20, the cell's first atom, atoms | rcpNS << 12}: one scalar load - no look at cellStart (a second,
+    // dependent round trip), no integer divisions (the builder leaves slices per atom and their reciprocal in the header)
+    const int4 mx = ((const int4*)L.meta)[cell];
+    asm volatile("" ::: "memory");                                  // (what follows is issued behind the loads above, not in front of them)
+    // after a slack violation (one GPU) the clean-up launch stages every cell with the wider stencil: stand down
+    const bool violated = P.nranks == 1 && slack_violated(P, counts);
     int meta = mx.x;
     if (violated || cr >= nCellsRun || !list_usable(L, meta)) meta = -1;         // (a cell that does not walk its list is served by the clean-up launch)
     if (meta > 0)
     {
-        const int T = meta & 0xFFF, nIter = meta >> 12;
+        const int T = meta & 0xFFF, nIter = (meta >> 12) & 0xFF;
         const int ncy = P.nc[1], ncz = P.nc[2];
         const int lx = mx.y & 1023, cy = (mx.y >> 10) & 1023, cz = (mx.y >> 20) & 1023;
-        const int ib = cellStart[cell], ie = cellStart[cell + 1];
+        const int ib = mx.z;
         const double cc0 = (lx + P.cx0) * P.csz[0] + 0.5 * P.csz[0], cc1 = cy * P.csz[1] + 0.5 * P.csz[1], cc2 = cz * P.csz[2] + 0.5 * P.csz[2];
         const DevPot lj = pots[0];
         if (kTab)
@@ -126,11 +130,11 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
             }
         }
         // ---- the cell's own atoms: this wave serves atoms [wave * aw, wave * aw + aw) of the cell; lane = slot * NS + slice
-        const int ncell = ie - ib;                                     // 1 .. 64 W (cells with more keep no list)
+        const int ncell = mx.w & 0xFFF;                                // 1 .. 64 W (cells with more keep no list)
         const int aw = list_atoms_per_wave(ncell, W);
         const int nthis = max(0, min(aw, ncell - wave * aw));           // atoms of this wave (the last waves of a small cell may have none)
-        const int NS = list_slices(aw);
-        const int rcpNS = 65536 / NS + 1;
+        const int NS = (meta >> 20) & 63;                               // slices per atom, list_slices(aw), and 65536 / NS + 1: left in the header by the builder
+        const int rcpNS = mx.w >> 12;
         const int slot = (lane * rcpNS) >> 16, slice = lane - slot * NS;
         const bool validI = slot < nthis;
         const int myi = ib + wave * aw + slot;
@@ -161,11 +165,11 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
                 c.rad = ((MODE == 0 && P.use_radii) || MODE == 4) ? ld_f64(A.rad, j) : 0.0;
                 return c;
             };
-            auto put = [&](int u, uint32_t e, const Cand& c) {
+            auto put = [&](auto IMG, int u, uint32_t e, const Cand& c) {
                 // (the tile holds candLds records, not whole groups of 64: LDS per wave bounds the occupancy; the first four groups always fit)
                 if ((MULTI || u >= 4) && u * kWave + lane >= L.candLds) return;      // (one wave: its first four groups always fit, candLds >= 256)
                 double xj = c.x, yj = c.y, zj = c.z;
-                if (images)
+                if (decltype(IMG)::value)
                 {   // image code per axis: 0 -> -L, 1 -> 0, 2 -> +L (exact: the product is +-L or 0)
                     xj += (double)((int)((e >> 26) & 3u) - 1) * P.L[0];
                     yj += (double)((int)((e >> 28) & 3u) - 1) * P.L[1];
@@ -173,35 +177,32 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
                 }
                 char* const r = tb + (size_t)(u * kWave + lane + 1) * RECB;       // candidate k -> record k + 1 (record 0 is the dummy)
                 *(double*)r = xj - cc0; *(double*)(r + 8) = yj - cc1; *(double*)(r + 16) = zj - cc2;
-                if (MODE == 1 && (P.pad0 & 4))
-                {   // (LDS experiment, timing only: every candidate sits in a small cluster above the cell, within reach of all its atoms)
-                    const int n = u * kWave + lane;
-                    *(double*)r = 0.1 * (n % 7) - 0.3; *(double*)(r + 8) = 0.1 * ((n / 7) % 7) - 0.3; *(double*)(r + 16) = 6.4 + 0.01 * (n % 11);
-                }
                 if (kTab) ttypT[u * kWave + lane + 1] = (uint8_t)c.typ;
                 if (kRadii) trad[u * kWave + lane + 1] = c.rad;
                 if (MODE == 0) ttyp0[u * kWave + lane + 1] = (uint8_t)c.typ;
             };
-            // this wave's groups are wave + q W, q = 0, 1, ...
-            const Cand c0 = fetch(ent[0]), c1 = fetch(ent[1]), c2 = fetch(ent[2]), c3 = fetch(ent[3]);
-            if (T > 4 * W * kWave)
-            {
-                const Cand c4 = fetch(ent[4]);
-                put(wave, ent[0], c0); put(wave + W, ent[1], c1); put(wave + 2 * W, ent[2], c2); put(wave + 3 * W, ent[3], c3); put(wave + 4 * W, ent[4], c4);
-                // dense systems: the rest of the tile, four groups per round trip
+            // this wave's groups are wave + q W, q = 0, 1, ...  Five of them are gathered whatever T is - straight-line code, fifteen loads in flight together
+            // (the builder fills all five groups of the array: behind the last candidate with the cell's first atom, one cache line for the whole wave)
+            const Cand c0 = fetch(ent[0]), c1 = fetch(ent[1]), c2 = fetch(ent[2]), c3 = fetch(ent[3]), c4 = fetch(ent[4]);
+            using ImgYes = std::integral_constant<bool, true>;
+            using ImgNo = std::integral_constant<bool, false>;
+            // (two copies of the straight-line code rather than a wave-uniform branch inside every put: interior cells - nearly all - shift nothing)
+            if (images) { put(ImgYes(), wave, ent[0], c0); put(ImgYes(), wave + W, ent[1], c1); put(ImgYes(), wave + 2 * W, ent[2], c2); put(ImgYes(), wave + 3 * W, ent[3], c3); put(ImgYes(), wave + 4 * W, ent[4], c4); }
+            else { put(ImgNo(), wave, ent[0], c0); put(ImgNo(), wave + W, ent[1], c1); put(ImgNo(), wave + 2 * W, ent[2], c2); put(ImgNo(), wave + 3 * W, ent[3], c3); put(ImgNo(), wave + 4 * W, ent[4], c4); }
+            if (T > kListPreload * W * kWave)
+            {   // dense systems: the rest of the tile, four groups per round trip
                 for (int q0 = kListPreload; (wave + q0 * W) * kWave < T; q0 += 4)
                 {
                     uint32_t en[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) en[q] = ((wave + (q0 + q) * W) * kWave < T) ? myList[(wave + (q0 + q) * W) * kWave] : ent[0];
                     const Cand d0 = fetch(en[0]), d1 = fetch(en[1]), d2 = fetch(en[2]), d3 = fetch(en[3]);
-                    put(wave + q0 * W, en[0], d0);
-                    if ((wave + (q0 + 1) * W) * kWave < T) put(wave + (q0 + 1) * W, en[1], d1);
-                    if ((wave + (q0 + 2) * W) * kWave < T) put(wave + (q0 + 2) * W, en[2], d2);
-                    if ((wave + (q0 + 3) * W) * kWave < T) put(wave + (q0 + 3) * W, en[3], d3);
+                    put(ImgYes(), wave + q0 * W, en[0], d0);           // (image code 1 on every axis shifts by exactly 0)
+                    if ((wave + (q0 + 1) * W) * kWave < T) put(ImgYes(), wave + (q0 + 1) * W, en[1], d1);
+                    if ((wave + (q0 + 2) * W) * kWave < T) put(ImgYes(), wave + (q0 + 2) * W, en[2], d2);
+                    if ((wave + (q0 + 3) * W) * kWave < T) put(ImgYes(), wave + (q0 + 3) * W, en[3], d3);
                 }
             }
-            else { put(wave, ent[0], c0); put(wave + W, ent[1], c1); put(wave + 2 * W, ent[2], c2); put(wave + 3 * W, ent[3], c3); }
         }
         // idle atom slots sit far away on the other side of the dummy candidate, so that nothing they meet is inside a cut-off
         const double xi = validI ? xr - cc0 : 1e30, yi = validI ? yr - cc1 : 1e30, zi = validI ? zr - cc2 : 1e30;
@@ -249,7 +250,6 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
                 if (t >= nIter) break;                                  // wave-uniform
                 uint32_t kn = ((u + 1) & 1) ? (ww[(u + 1) >> 1] >> 16) : (ww[(u + 1) >> 1] & 0xFFFFu);      // byte offset of the next candidate's record
                 if (u == 7 && c + 1 >= nChunks) kn = dummyOff;           // (behind the list's last chunk there is nothing the builder wrote: stale entries of an older, larger tile)
-                if (MODE == 1 && (P.pad0 & 8)) kn = (uint32_t)((((lane + 4 * t) & 31) + 1 + 32 * ((t >> 3) & 7)) * 24);       // (LDS experiment: 32 distinct bank pairs per half wave)
                 double xn, yn, zn, radn = 0.0;
                 int tn = 0;
                 fetch(kn, xn, yn, zn, tn, radn);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
             const double fxi = -q * P.E[0] + acc.fx;   // clear_force integrators.cpp:17-39
             const double fyi = -q * P.E[1] + acc.fy;
             const double fzi = -q * P.E[2] + acc.fz;
-            if (!(MODE == 1 && (P.pad0 & 12))) { A.fx[myi] = fxi; A.fy[myi] = fyi; A.fz[myi] = fzi; }
+            A.fx[myi] = fxi; A.fy[myi] = fyi; A.fz[myi] = fzi;
             if (P.fuseKick || N.xn)
             {   // second half-kick + kinetic energy of integrate2 (integrators.cpp:486-531 ; verlet_2stage cuMDfunc.cu:521-600); with NextStep also the
                 // next step's k_integrate1_bin<2>
@@ -381,20 +381,43 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
     if (cr >= nCellsRun) return;
     const int cell = firstCell + cr;
     const int ncy = P.nc[1], ncz = P.nc[2];
-    const int cxyz = L.meta[2 * cell + 1];
+    const int cxyz = L.meta[4 * cell + 1];
     const int lx = cxyz & 1023, cy = (cxyz >> 10) & 1023, cz = (cxyz >> 20) & 1023;
     const int ib = cellStart[cell], ie = cellStart[cell + 1];
     const int nthis = ie - ib;
-    if (nthis == 0) { if (lane == 0) L.meta[2 * cell] = 0; return; }            // an empty cell: a list with nothing in it
-    auto no_list = [&](int why) { if (lane == 0) { L.meta[2 * cell] = -1; atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); if (why) atomicAdd(&L.noList[why], 1); } };
+    if (nthis == 0) { if (lane == 0) L.meta[4 * cell] = 0; return; }            // an empty cell: a list with nothing in it
+    auto no_list = [&](int why) { if (lane == 0) { L.meta[4 * cell] = -1; atomicAdd(&L.noList[0], 1); atomicAdd(&L.noList[2], 1); if (why) atomicAdd(&L.noList[why], 1); } };
     if (nthis > kWave * W) { no_list(0); return; }                 // (W waves of k_pair_list share the cell: up to 64 atoms each)
     const int RECB = L.entryScale;                                  // record number -> list entry (k_pair_list's mode decides: byte offset or number)
     const int candLds = L.candLds;
-    const float hf0 = (float)(0.5 * P.csz[0]), hf1 = (float)(0.5 * P.csz[1]), hf2 = (float)(0.5 * P.csz[2]);
     const float cs0 = (float)P.csz[0], cs1 = (float)P.csz[1], cs2 = (float)P.csz[2];
     // f32 pruning radius: the list radius + what rounding can do to a coordinate (an atom's own-cell offset is rounded to f32, |x| < a few cell edges:
     // 2^-22 relative on the square is far more than that)
     const float pruneF = (float)(P.pruneR2 * (1.0 + 1e-5));
+    // The candidates are pruned against the bounding box of the cell's ATOMS, not against the cell: a dozen atoms leave on average an eighth of the cell's
+    // edge empty on either side, and the box dilated by the list radius holds 15 % fewer candidates (C4: 299 -> 255) - less to filter here, and in
+    // k_pair_list a smaller LDS tile (its occupancy), a fifth group of candidates that is mostly padding, shorter gathers.  Conservative: an atom farther than
+    // the list radius from the box is farther than that from every atom inside it.
+    float bc0, bc1, bc2, bh0, bh1, bh2;
+    {
+        float lo0 = 3e38f, lo1 = 3e38f, lo2 = 3e38f, hi0 = -3e38f, hi1 = -3e38f, hi2 = -3e38f;
+        for (int a = lane; a < nthis; a += kWave)
+        {
+            const float4 m = L.rel[ib + a];
+            lo0 = fminf(lo0, m.x); hi0 = fmaxf(hi0, m.x); lo1 = fminf(lo1, m.y); hi1 = fmaxf(hi1, m.y); lo2 = fminf(lo2, m.z); hi2 = fmaxf(hi2, m.z);
+        }
+#pragma unroll
+        for (int o = kWave >> 1; o >= 1; o >>= 1)
+        {
+            lo0 = fminf(lo0, __shfl_xor(lo0, o, kWave)); hi0 = fmaxf(hi0, __shfl_xor(hi0, o, kWave));
+            lo1 = fminf(lo1, __shfl_xor(lo1, o, kWave)); hi1 = fmaxf(hi1, __shfl_xor(hi1, o, kWave));
+            lo2 = fminf(lo2, __shfl_xor(lo2, o, kWave)); hi2 = fmaxf(hi2, __shfl_xor(hi2, o, kWave));
+        }
+        // (half-widths rounded up by more than the f32 error of centre and difference)
+        bc0 = 0.5f * (lo0 + hi0); bh0 = 0.5f * (hi0 - lo0) * 1.000001f + 1e-5f;
+        bc1 = 0.5f * (lo1 + hi1); bh1 = 0.5f * (hi1 - lo1) * 1.000001f + 1e-5f;
+        bc2 = 0.5f * (lo2 + hi2); bh2 = 0.5f * (hi2 - lo2) * 1.000001f + 1e-5f;
+    }
 
     // ---- staging: all z-runs are looked up by the lanes in parallel, packed into a table, loaded eight at a time
     int T = 0;
@@ -466,8 +489,8 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
                         const float offx = (float)(((code >> 6) & 63) - 32) * cs0, offy = (float)(((code >> 12) & 63) - 32) * cs1;
                         const float dzc = (float)((((code >> 4) & 3) - 1) * ncz - cz);          // cells along z between the candidate's cell (its own index rides in .w) and this one
                         const float xf = g[u].x + offx, yf = g[u].y + offy, zf = fmaf(g[u].w + dzc, cs2, g[u].z);
-                        // distance from the cell's box: atoms farther than the list radius cannot be anybody's partner
-                        const float bx = fmaxf(fabsf(xf) - hf0, 0.0f), by = fmaxf(fabsf(yf) - hf1, 0.0f), bz = fmaxf(fabsf(zf) - hf2, 0.0f);
+                        // distance from the box of the cell's atoms: atoms farther than the list radius cannot be anybody's partner
+                        const float bx = fmaxf(fabsf(xf - bc0) - bh0, 0.0f), by = fmaxf(fabsf(yf - bc1) - bh1, 0.0f), bz = fmaxf(fabsf(zf - bc2) - bh2, 0.0f);
                         const bool keep = (lane < gjn[u]) && (bx * bx + by * by + bz * bz) <= pruneF;
                         const unsigned long long mask = __ballot(keep);
                         const int nk = __popcll(mask);
@@ -494,7 +517,7 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
     // ---- candidates: written out in whole groups of 64 (k_pair_list gathers whole groups: the last one is filled with a valid atom, the cell's first)
     {
         uint32_t* const myList = L.cand + (size_t)cell * L.candCap;
-        const int Tpad = (T + kWave - 1) & ~(kWave - 1);
+        const int Tpad = max((T + kWave - 1) & ~(kWave - 1), kListPreload * W * kWave);      // (k_pair_list gathers five groups per wave whatever T is)
         for (int q = lane; q < Tpad; q += kWave) myList[q] = (q < T) ? tent[q] : ((uint32_t)ib | (0x15u << 26));
     }
     // far-away, finite dummies behind the last candidate up to the end of its mask word: the filter reads whole words of 8 x 16 candidates, without guards
@@ -626,7 +649,11 @@ __global__ __launch_bounds__(kWave) void k_build_lists(StepParams P, const int32
     }
     if (lane == 0)
     {
-        L.meta[2 * cell] = usable ? (T | (nIter << 12)) : -1;
+        // header: candidates | iterations << 12 | slices per atom << 20 ; then the cell's first atom and atoms | (65536 / slices + 1) << 12 - all k_pair_list needs to
+        // know about the cell arrives in one 16-byte scalar load
+        L.meta[4 * cell] = usable ? (T | (nIter << 12) | (NS << 20)) : -1;
+        L.meta[4 * cell + 2] = ib;
+        L.meta[4 * cell + 3] = nthis | (rcpNS << 12);
         if (T > L.noList[3]) atomicMax(&L.noList[3], T);           // (a read first: after the first few cells nobody has a new record to report)
         if (usable && nIter > L.noList[4]) atomicMax(&L.noList[4], nIter);
         if (P.pad0 & 2097152) { atomicAdd(&L.noList[8], nIter); atomicAdd(&L.noList[9], T); atomicAdd(&L.noList[10], nthis); }      // measurement aid (slow)

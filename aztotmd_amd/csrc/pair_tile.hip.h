@@ -374,7 +374,8 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
 struct PairLists
 {
     uint32_t* cand = nullptr;      // [nCell][candCap]: atom index | image code << 26 of every candidate, in tile order; padded with valid entries to a multiple of 64
-    int32_t* meta = nullptr;       // [nCell][2]: {candidates T | list iterations << 12, cell coordinates lx | cy << 10 | cz << 20 (written once by the host)} ;
+    int32_t* meta = nullptr;       // [nCell][4]: {candidates T | list iterations << 12 | slices per atom << 20, cell coordinates lx | cy << 10 | cz << 20 (written once by the host),
+                                   //          the cell's first atom, atoms in the cell | (65536 / slices + 1) << 12} ;
                                    //          first word -1: this cell keeps no list (more candidates than the tile holds, more than 64 atoms, or more
                                    //          iterations than iterCap) - such cells are staged in full on every step by the clean-up launch
     uint16_t* pairs = nullptr;     // [nCell][iterCap * 64]: chunks of 8 iterations x 64 lanes; an entry is the byte offset of the candidate's record in the LDS tile
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 || MODE == 3 || MODE == 5) ? 3 : 
         const int myRow = rowBase + lane * rowStep;
         const int myCr = (blockIdx.x & 7) * per + myRow;
         bool need = myRow < per && myCr < nCellsRun;
-        if (!widened && need) need = !list_usable(L, L.meta[2 * (firstCell + myCr)]);
+        if (!widened && need) need = !list_usable(L, L.meta[4 * (firstCell + myCr)]);
         todo = __ballot(need);
     }
     else if ((blockIdx.x & 7) * per + rowBase >= nCellsRun) todo = 0ULL;
