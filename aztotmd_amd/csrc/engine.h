@@ -93,7 +93,7 @@ private:
     void launch_ewald();
     void sort_and_forces(int stepMode, bool withBonded = true);   // 0: bin + sort + forces (aztot_forces), 1: a step that re-sorts, 2: a plain step of the lazy re-sort
     void launch_step_kernels();
-    void adapt_sort_interval();
+    bool adapt_sort_interval();
     void run_steps(int nsteps);
     void launch_pair();
     int pair_variant() const;
@@ -237,6 +237,22 @@ private:
     hipEvent_t evUnlisted_ = nullptr;
     int unlistedState_ = 0;         // 0 unknown (copy in flight or never made), 1 known to be zero, 2 known to be non-zero
     bool carryAgreed_ = false;      // slab ranks: every rank can carry the interval on (decided together at the end of the previous call)
+    // Slab ranks cannot repair a skin violation on the spot (they hold hw ghost layers: no wider stencil to fall back on), and the host learns of one only
+    // at its next look.  So every look that finds none leaves a snapshot of the dynamic state (per-atom arrays, DevStats, Counts, partial sums - what an
+    // exact restart needs, device to device), and a look that finds one goes back to it and runs the steps since again with the cells rebuilt every
+    // step, which is exact whatever the speeds (all ranks together: the verdict is all-reduced).  A violation costs time, never exactness.
+    struct Snapshot
+    {
+        AtomArrays A{};
+        void *stats = nullptr, *counts = nullptr;
+        double* partials = nullptr;
+        BufState buf{};
+        bool valid = false;
+    } snap_;
+    long long stepsSinceSnap_ = 0;
+    bool rollback_on() const { return nranks_ > 1 && lazyOn_; }
+    void take_snapshot();
+    void replay_from_snapshot();
     void prepare_next_call();
 };
 

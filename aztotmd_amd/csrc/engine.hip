@@ -501,7 +501,8 @@ void Engine::allocate()
             if (P_.nc[k] < 2 * (P_.hw[k] + 1) + 1) widenOk = false;
         }
         const int sortEvery = opt_.sort_every;                    // 0: adaptive, 1: every step (the reference's schedule), n: at most every n-th step
-        // (a slab rank cannot widen its stencil - it holds hw ghost layers - so there a violation is an error and the interval keeps a factor 4 in hand)
+        // (a slab rank cannot widen its stencil - it holds hw ghost layers -: there a violation is repaired by going back to the last look's snapshot and
+        //  running the window again with the cells rebuilt every step, Engine::replay_from_snapshot; the interval keeps a factor 2 in hand)
         lazyOn_ = sortEvery != 1 && opt_.pair_variant != 3 && (widenOk || nranks_ > 1) && m.rMax > 0 && slack > 1e-3 && m.E[0] == 0.0 && m.E[1] == 0.0 &&
                   m.E[2] == 0.0 && pair_tile_supported(P_);
         lazyCap_ = sortEvery > 1 ? std::min(sortEvery, kLazyCapMax) : kLazyCapMax;
@@ -1133,6 +1134,7 @@ void Engine::collect_and_finalize(unsigned slotMask)
 
 void Engine::forces(bool withBonded)
 {
+    snap_.valid = false;
     sinceSort_ = 1 << 30;           // a sort interval does not run on through a force call (it re-bins wrapped coordinates)
     sort_and_forces(0, withBonded);
     sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false;
@@ -1233,6 +1235,60 @@ void Engine::finish_steps()
     collect_and_finalize(mask);
 }
 
+// Slab ranks: the dynamic state as it stands (the host has just looked and found no skin violation), device to device.  The arrays are those an exact
+// restart needs (aztot_state + aztot_clock): everything else is rebuilt by the step that rebuilds the cells, and the replay opens with one.
+void Engine::take_snapshot()
+{
+    const size_t nd = sizeof(double) * (size_t)capacity_, ni = sizeof(int32_t) * (size_t)capacity_;
+    if (!snap_.A.x)
+    {
+        auto alloc = [&](size_t bytes) { void* p = nullptr; HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16))); allocs_.push_back(p); return p; };
+        double** d[] = {&snap_.A.x, &snap_.A.y, &snap_.A.z, &snap_.A.vx, &snap_.A.vy, &snap_.A.vz, &snap_.A.fx, &snap_.A.fy, &snap_.A.fz, &snap_.A.U, &snap_.A.rad};
+        for (auto pp : d) *pp = (double*)alloc(nd);
+        snap_.A.type = (int32_t*)alloc(ni); snap_.A.id = (int32_t*)alloc(ni);
+        snap_.stats = alloc(sizeof(DevStats)); snap_.counts = alloc(sizeof(Counts));
+        snap_.partials = (double*)alloc(sizeof(double) * (size_t)PS_COUNT * maxBlocks_);
+    }
+    const AtomArrays& A = cur();
+    const double* src[] = {A.x, A.y, A.z, A.vx, A.vy, A.vz, A.fx, A.fy, A.fz, A.U, A.rad};
+    double* dst[] = {snap_.A.x, snap_.A.y, snap_.A.z, snap_.A.vx, snap_.A.vy, snap_.A.vz, snap_.A.fx, snap_.A.fy, snap_.A.fz, snap_.A.U, snap_.A.rad};
+    for (int k = 0; k < 11; k++) HIP_CHECK(hipMemcpyAsync(dst[k], src[k], nd, hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(snap_.A.type, A.type, ni, hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(snap_.A.id, A.id, ni, hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(snap_.stats, dStats_, sizeof(DevStats), hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(snap_.counts, dCounts_, sizeof(Counts), hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(snap_.partials, dPartials_, sizeof(double) * (size_t)PS_COUNT * maxBlocks_, hipMemcpyDeviceToDevice, stream_));
+    snap_.buf = buf_state();
+    snap_.valid = true;
+    stepsSinceSnap_ = 0;
+}
+
+// ... and back to it: the steps since the snapshot run again with the cells rebuilt on every one of them (no atom can leave a slack that is never used)
+void Engine::replay_from_snapshot()
+{
+    if (!snap_.valid) throw std::runtime_error("lazy re-sort on slab ranks: an atom left its cell's slack and there is no snapshot to go back to");
+    sync();
+    destroy_graphs(); graphCycle_ = 0;
+    set_buf_state(snap_.buf);
+    const size_t nd = sizeof(double) * (size_t)capacity_, ni = sizeof(int32_t) * (size_t)capacity_;
+    const AtomArrays& A = cur();
+    double* dst[] = {A.x, A.y, A.z, A.vx, A.vy, A.vz, A.fx, A.fy, A.fz, A.U, A.rad};
+    const double* src[] = {snap_.A.x, snap_.A.y, snap_.A.z, snap_.A.vx, snap_.A.vy, snap_.A.vz, snap_.A.fx, snap_.A.fy, snap_.A.fz, snap_.A.U, snap_.A.rad};
+    for (int k = 0; k < 11; k++) HIP_CHECK(hipMemcpyAsync(dst[k], src[k], nd, hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(A.type, snap_.A.type, ni, hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(A.id, snap_.A.id, ni, hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(dStats_, snap_.stats, sizeof(DevStats), hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(dCounts_, snap_.counts, sizeof(Counts), hipMemcpyDeviceToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(dPartials_, snap_.partials, sizeof(double) * (size_t)PS_COUNT * maxBlocks_, hipMemcpyDeviceToDevice, stream_));
+    sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false; preIntegrated_ = false; haloInfoPending_ = false; unlistedState_ = 0;
+    kickOwed_ = false;
+    if (lazyK_ != 1) lazyK_ = 1;
+    const long long n = stepsSinceSnap_;
+    if (std::getenv("AZTOT_VERBOSE")) std::fprintf(stderr, "aztot: rank %d: skin violation on a slab rank - %lld steps run again with the cells rebuilt every step\n", rank_, n);
+    if (n > 0) run_steps((int)n);
+    stepsSinceSnap_ = n;
+}
+
 void Engine::step(int nsteps)
 {
     if (nsteps <= 0) return;
@@ -1240,7 +1296,9 @@ void Engine::step(int nsteps)
     // call and, inside long calls, whenever lazyWindow_ steps have gone by since the last look - 8, 16, 32, ... then every 256 (a run that starts from rest speeds
     // up for a while: the looks are close together where that happens).  The count runs on across calls (sinceLook_), and a look is skipped when the call
     // ends within half a window anyway: a short call right behind a look - the driver's 20 steps after 5 of warm-up - pays for no look of its own.
-    const int windowCap = nranks_ > 1 ? 64 : 256;     // (slab ranks cannot repair a slack violation, only report it: they look more often)
+    const int windowCap = nranks_ > 1 ? 64 : 256;     // (a slab rank repairs a skin violation by running the window again: it looks more often)
+    const bool roll = rollback_on();
+    if (roll && !snap_.valid) take_snapshot();         // (the state as the caller left it: set_state / aztot_forces / the first call)
     int left = nsteps;
     while (left > 0)
     {
@@ -1248,16 +1306,23 @@ void Engine::step(int nsteps)
         run_steps(n);
         left -= n;
         sinceLook_ += n;
+        stepsSinceSnap_ += n;
         if (left > 0 && sinceLook_ >= lazyWindow_)
         {
             if (2 * left > lazyWindow_)
             {
                 sync();
-                adapt_sort_interval();
+                if (!adapt_sort_interval())
+                {   // (slab ranks, all together) an atom left its slack somewhere since the snapshot: those steps again, exactly, then a look that cannot fail
+                    replay_from_snapshot();
+                    sync();
+                    if (!adapt_sort_interval()) throw std::runtime_error("lazy re-sort: a skin violation in a run that rebuilds its cells every step");
+                }
+                if (roll) take_snapshot();
                 sinceLook_ = 0;
                 lazyWindow_ = std::min(windowCap, 2 * lazyWindow_);
             }
-            else { run_steps(left); sinceLook_ += left; left = 0; }      // the end of the call, at most half a window away, is the look
+            else { run_steps(left); sinceLook_ += left; stepsSinceSnap_ += left; left = 0; }      // the end of the call, at most half a window away, is the look
         }
     }
     kickOwed_ = lazyKick_;          // set here, not in launch_step_kernels: a replayed graph does not pass through the host code
@@ -1267,9 +1332,19 @@ void Engine::step(int nsteps)
     check_overflow();
     if (lazyOn_)
     {
-        adapt_sort_interval();
+        if (!adapt_sort_interval())
+        {
+            replay_from_snapshot();
+            kickOwed_ = lazyKick_;
+            finish_steps();
+            check_launch("step kernels (run again)");
+            sync();
+            check_overflow();
+            if (!adapt_sort_interval()) throw std::runtime_error("lazy re-sort: a skin violation in a run that rebuilds its cells every step");
+        }
         if (2 * sinceLook_ >= lazyWindow_) lazyWindow_ = std::min(windowCap, 2 * lazyWindow_);      // (this look stands in for the one that was due)
         sinceLook_ = 0;
+        if (roll) take_snapshot();
     }
     prepare_next_call();
 }
@@ -1439,8 +1514,9 @@ void Engine::prepare_next_call()
 // the largest step any atom made since the last look sizes the next calls' sort interval: K steps of that length use at most two thirds of the slack
 // (one GPU; a violation is handled exactly by the clean-up launch at the staging kernel's speed, so the margin is a performance choice: with half the
 // slack C4 ran at K = 16, with two thirds at K = 24-28, no violation in 2 000 steps; every violation widens the margin for good - a system that heats up,
-// like the Born-Mayer-Huggins melt B3, would otherwise run into one after the other) - a quarter on slab ranks, which cannot widen their stencil
-void Engine::adapt_sort_interval()
+// like the Born-Mayer-Huggins melt B3, would otherwise run into one after the other) - half on slab ranks, whose repair (a window of steps run again) is dearer.
+// Returns false when the slab ranks have found a violation: the caller takes every rank back to its snapshot
+bool Engine::adapt_sort_interval()
 {
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
@@ -1531,9 +1607,11 @@ void Engine::adapt_sort_interval()
         {
             const int32_t z = 0;
             HIP_CHECK(hipMemcpy(&dCounts_->lazyViolatedEver, &z, sizeof(z), hipMemcpyHostToDevice));
-            lazyK_ = 1; lazyMeasured_ = false; lazyWindow_ = 8; sinceLook_ = 0; lazyViolations_++;
-            throw std::runtime_error("lazy re-sort on slab ranks: an atom left its cell's slack between two sorts (the speeds grew more than fourfold within one "
-                                     "interval); the forces of this call are not exact - restart from the last state with options.sort_every = 1");
+            if (lazyK_ != 1) { lazyK_ = 1; destroy_graphs(); graphCycle_ = 0; }
+            lazyMeasured_ = false; lazyWindow_ = 8; sinceLook_ = 0; lazyViolations_++;
+            lazyMargin_ = std::min(4.0, lazyMargin_ * (4.0 / 3.0));
+            if (rebuildNeeded) { sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false; }
+            return false;             // every rank goes back to its snapshot (Engine::step)
         }
     }
     HIP_CHECK(hipMemsetAsync(&dCounts_->maxStep2, 0, sizeof(unsigned long long), stream_));      // (in stream order: no second round trip for the look)
@@ -1566,7 +1644,9 @@ void Engine::adapt_sort_interval()
             double ms2;
             std::memcpy(&ms2, &c.maxStep2, sizeof(ms2));
             const double len = std::sqrt(ms2);
-            const double raw = len > 0 ? lazySlack_ / ((nranks_ > 1 ? 4.0 : lazyMargin_) * len) : 1e9;
+            // (slab ranks repair a violation by running up to a window of steps again with the cells rebuilt every step - dearer than the wider stencil one GPU
+            //  falls back on - so they keep a factor 2 in hand at least; round 2 kept 4 and could only report the violation)
+            const double raw = len > 0 ? lazySlack_ / ((nranks_ > 1 ? std::max(2.0, lazyMargin_) : lazyMargin_) * len) : 1e9;
             if (std::getenv("AZTOT_VERBOSE"))
                 std::fprintf(stderr, "aztot: longest step %.3e A, slack %.3e A, margin %.2f%s: interval up to %.1f steps\n", len, lazySlack_, lazyMargin_, violated ? ", violated" : "", raw);
             static const int allowed[] = {64, 56, 48, 40, 36, 32, 28, 24, 20, 16, 14, 12, 10, 8, 6, 5, 4, 3, 2, 1};
@@ -1578,6 +1658,7 @@ void Engine::adapt_sort_interval()
         else if (fromSpeed > 0) K = fromSpeed;
     }
     if (K != lazyK_) { lazyK_ = K; destroy_graphs(); graphCycle_ = 0; }
+    return true;
 }
 
 void Engine::check_overflow()
@@ -1712,6 +1793,7 @@ void Engine::get_clock(aztot_clock& out)
 void Engine::set_clock(const aztot_clock& in)
 {
     sync();
+    snap_.valid = false;
     DevStats s;
     HIP_CHECK(hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost));
     s.step = in.step; s.stepAtSort = in.step; s.chit = in.nose_chit; s.conint = in.nose_conint; s.ekSim = in.eng_kin; s.engKin = in.eng_kin;
@@ -1747,6 +1829,7 @@ int Engine::cell_table(int32_t dims[3], int32_t* cellStart, int capCells, int32_
 void Engine::set_state(const aztot_state& in)
 {
     sync();
+    snap_.valid = false;
     sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false;       // the next call rebuilds the cells
     if (in.vx || in.vy || in.vz || in.fx || in.fy || in.fz)
     {   // new velocities / forces: the interval measured on the old ones says nothing about them - every step rebuilds until the first look

@@ -103,7 +103,7 @@ def main():
         return
     def heat(e):
         # a heating protocol between two calls: velocities x 3 through aztot_set_state.  The sort interval measured on the slow atoms must not be carried
-        # over (a slab rank cannot repair a skin violation, only report it): set_state forgets it, every step rebuilds until the next look
+        # over (a slab rank repairs a skin violation by running a window of steps again - exact, but slow): set_state forgets it, every step rebuilds until the next look
         sv = e.state(("vx", "vy", "vz"))
         e.set_state(**{k: np.nan_to_num(sv[k], nan=0.0) * 3.0 for k in ("vx", "vy", "vz")})
 
@@ -131,7 +131,7 @@ def main():
         rs, rst = ref.state(), ref.stats()
         from util import rel_err
         errs = {k: rel_err(merged[k], rs[k]) for k in keys if np.abs(rs[k]).max() > 0}
-        out = {"world": world, "transport": transport, "rccl_ranks": eng.comm_ranks(), "n_atoms": len(case["types"]), "sort_interval": st["sort_interval"], "pair_lists": st["pair_lists"], "cells_without_list": st["cells_without_list"], "owned_total": owned_total,
+        out = {"world": world, "transport": transport, "rccl_ranks": eng.comm_ranks(), "n_atoms": len(case["types"]), "sort_interval": st["sort_interval"], "sort_violations": st["sort_violations"], "pair_lists": st["pair_lists"], "cells_without_list": st["cells_without_list"], "owned_total": owned_total,
                "every_atom_owned_once": bool((cover == 1).all()), "max_rel_err_vs_single": max(errs.values()), "errs": errs,
                "energy_rel": {k: abs(st[k] - rst[k]) / (abs(rst[k]) + 1e-300) for k in ("engTot", "engVdW", "engKin", "engCoul", "engTemp", "engBond", "engAngle", "engCoulRec", "engCoulConst") if abs(rst[k]) > 0},
                "cross": [st["negCross"], st["posCross"], rst["negCross"], rst["posCross"]],

@@ -79,10 +79,27 @@ def test_slabs_on_random_dynamics(seed, nranks):
 
 def test_slabs_survive_a_heating_step_between_two_calls():
     """aztot_set_state with faster velocities between two aztot_step calls (a heating protocol, a restart): the interval measured on the slow atoms is
-    forgotten (every step rebuilds until the next look), so the slab ranks - which cannot repair a skin violation, only report it - stay exact."""
+    forgotten (every step rebuilds until the next look), so the slab ranks do not run into a skin violation they would have to repair by running a
+    window of steps again."""
     out = run_ranks(2, "heat", 45, port=29623)
     assert out["every_atom_owned_once"] and out["max_rel_err_vs_single"] < 1e-9, out["errs"]
     assert all(v < 1e-10 for v in out["energy_rel"].values()), out["energy_rel"]
+
+
+@pytest.mark.parametrize("name,nranks,nsteps,port", [("hot", 2, 70, 29626), ("hot", 3, 45, 29627), ("thermo", 2, 40, 29628)])
+def test_slab_ranks_repair_a_skin_violation_by_running_the_window_again(name, nranks, nsteps, port):
+    """A slab rank holds hw ghost layers, so it cannot fall back on a wider stencil when an atom leaves its cell's slack between two sorts.  Debug bit 8192
+    holds the interval at 32 steps on atoms far too fast for it: the look that finds the violation takes every rank back to the snapshot the last clean look
+    left (per-atom arrays, DevStats, Counts, partial sums - device to device) and runs the steps since again with the cells rebuilt every step.  The result
+    must equal the single-rank engine's (which repairs its own violations with the wider stencil): x / v / f 1e-9, energies, wall counters, and - 'thermo' -
+    the radiative thermostat's per-atom state and random numbers."""
+    out = run_ranks(nranks, name, nsteps, extra={"sort_every": 32, "debug": 8192}, port=port)
+    assert out["every_atom_owned_once"] and out["owned_total"] == out["n_atoms"]
+    assert out["max_rel_err_vs_single"] < 1e-9, out["errs"]
+    assert all(v < 1e-10 for v in out["energy_rel"].values()), out["energy_rel"]
+    assert out["cross"][0] == out["cross"][2] and out["cross"][1] == out["cross"][3] and out["species_cross_equal"]
+    if name == "hot":
+        assert out["sort_violations"] > 0, out
 
 
 def test_slabs_with_several_waves_per_cell():
