@@ -146,6 +146,8 @@ struct StepParams
                                   // 0: the cells are rebuilt every step
     double pruneR2;               // tile kernels: atoms farther than this (squared) from the centre cell's box are not staged: (rc + 2 slack)^2
     double ljDropR2;              // single_lj: r^2 beyond which |f| <= 1e5 is certain, so the 'pair dropped' rule (integrators.cpp:170) need not be evaluated
+    int32_t optimistic, pad3;     // 1: no clean-up launch follows k_pair_list (small systems on one GPU, Engine::step): it walks its lists whatever the violation flag
+                                  //    says; a look that finds a violation - or a cell without a list - goes back to the snapshot and runs the window again with the launch
 };
 
 // reduction slots of the per-block partial buffer (deterministic two-stage sums)

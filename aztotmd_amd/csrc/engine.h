@@ -35,8 +35,7 @@ namespace aztot {
 enum DebugBit : unsigned
 {
     DBG_BUILD_PHASE_MASK = 3,            // NOT result-preserving (phase timing of k_build_lists): 1 staging only, 2 + candidates and filter, 3 + compaction
-    DBG_LDS_FAKE_TILE = 4,               // NOT result-preserving (LDS experiment, one-species LJ list kernel): every candidate in a small cluster above the cell, forces not stored
-    DBG_LDS_NO_CONFLICTS = 8,            // NOT result-preserving (with 4): list entries replaced by 32 distinct bank pairs per half wave
+    DBG_ALWAYS_CLEANUP = 4,              // the clean-up launch behind every k_pair_list whatever the system size (small systems on one GPU run without it: Engine::choose_optimism)
     DBG_KICK_EVERY_STEP = 128,           // k_integrate2 launched every step
     DBG_LARGE_KICK_PATH = 256,           // the deferred half-kick of large systems whatever the size
     DBG_GENERIC_PAIR = 512,              // the generic (switch-based) pair body instead of a specialised mode
@@ -250,7 +249,15 @@ private:
         bool valid = false;
     } snap_;
     long long stepsSinceSnap_ = 0;
-    bool rollback_on() const { return nranks_ > 1 && lazyOn_; }
+    // One GPU, small systems (a step is a handful of microsecond kernels: the clean-up launch behind every k_pair_list is a quarter of a 40 000-atom step and
+    // nearly always has nothing to do): the same snapshots let the plain steps run WITHOUT it.  A look that finds a violation or a cell that kept no list
+    // goes back and runs the window again with the launch in place (exact as before), and the run stays on the safe side for a few looks.
+    bool optimistic_ = false;
+    int safeLooks_ = 2;             // looks still to be spent with the clean-up launch in place (an engine's first two; 8, 16, 32 ... after a window had to be run again)
+    int rollbacks_ = 0;
+    bool unlistedAtLook_ = false;   // the last look found cells recorded without a list
+    void choose_optimism();
+    bool rollback_on() const { return lazyOn_ && (nranks_ > 1 || optimistic_); }
     void take_snapshot();
     void replay_from_snapshot();
     void prepare_next_call();

@@ -931,7 +931,7 @@ void Engine::launch_pair()
                 }
                 else if (nranks_ > 1 && unlistedState_ == 0 && hUnlisted_ && !capturing_ && hipEventQuery(evUnlisted_) == hipSuccess)
                     unlistedState_ = (hUnlisted_[0] == 0) ? 1 : 2;
-                const bool skipCleanup = nranks_ > 1 && unlistedState_ == 1 && candMode_ == 2 && !capturing_;
+                const bool skipCleanup = (nranks_ > 1 && unlistedState_ == 1 && candMode_ == 2 && !capturing_) || optimistic_;
                 NextStep nx;
                 nx.st = dStats_; nx.cnt = dCounts_; nx.R0 = ref_;
                 if (fuseNext_) { nx.xn = altXyz_[cur_][0]; nx.yn = altXyz_[cur_][1]; nx.zn = altXyz_[cur_][2]; }
@@ -1235,6 +1235,21 @@ void Engine::finish_steps()
     collect_and_finalize(mask);
 }
 
+// may the plain steps of the next window run without the clean-up launch?  (decided at the start of a call and after every look: the answer is baked into
+// kernel arguments, so a change drops the captured graphs)
+void Engine::choose_optimism()
+{
+    const bool want = nranks_ == 1 && lazyOn_ && listsOn_ && lazyMeasured_ && lazyK_ > 1 && pair_variant() == 2 && capacity_ <= 2 * kFuseKickMaxAtoms &&
+                      safeLooks_ == 0 && !unlistedAtLook_ && unlistedState_ != 2 && !(debug_ & DBG_ALWAYS_CLEANUP);
+    if (want != optimistic_)
+    {
+        optimistic_ = want;
+        P_.optimistic = want ? 1 : 0;
+        destroy_graphs(); graphCycle_ = 0;
+        if (!want) snap_.valid = false;
+    }
+}
+
 // Slab ranks: the dynamic state as it stands (the host has just looked and found no skin violation), device to device.  The arrays are those an exact
 // restart needs (aztot_state + aztot_clock): everything else is rebuilt by the step that rebuilds the cells, and the replay opens with one.
 void Engine::take_snapshot()
@@ -1282,9 +1297,16 @@ void Engine::replay_from_snapshot()
     HIP_CHECK(hipMemcpyAsync(dPartials_, snap_.partials, sizeof(double) * (size_t)PS_COUNT * maxBlocks_, hipMemcpyDeviceToDevice, stream_));
     sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false; preIntegrated_ = false; haloInfoPending_ = false; unlistedState_ = 0;
     kickOwed_ = false;
-    if (lazyK_ != 1) lazyK_ = 1;
+    if (nranks_ > 1) { if (lazyK_ != 1) lazyK_ = 1; }
+    else
+    {   // one GPU: the same steps with the clean-up launch behind every k_pair_list (it stages the cells without a list and, from the step of a violation
+        // on, every cell with the wider stencil)
+        optimistic_ = false; P_.optimistic = 0;
+        rollbacks_ = std::min(rollbacks_ + 1, 12);
+        safeLooks_ = 4 << rollbacks_;          // 8, 16, 32 ... looks on the safe side: a system that keeps outgrowing its lists stops trying
+    }
     const long long n = stepsSinceSnap_;
-    if (std::getenv("AZTOT_VERBOSE")) std::fprintf(stderr, "aztot: rank %d: skin violation on a slab rank - %lld steps run again with the cells rebuilt every step\n", rank_, n);
+    if (std::getenv("AZTOT_VERBOSE")) std::fprintf(stderr, "aztot: rank %d: a skin violation (or a cell without a list) found at a look - %lld steps run again, %s\n", rank_, n, nranks_ > 1 ? "cells rebuilt every step" : "with the clean-up launch");
     if (n > 0) run_steps((int)n);
     stepsSinceSnap_ = n;
 }
@@ -1297,7 +1319,8 @@ void Engine::step(int nsteps)
     // up for a while: the looks are close together where that happens).  The count runs on across calls (sinceLook_), and a look is skipped when the call
     // ends within half a window anyway: a short call right behind a look - the driver's 20 steps after 5 of warm-up - pays for no look of its own.
     const int windowCap = nranks_ > 1 ? 64 : 256;     // (a slab rank repairs a skin violation by running the window again: it looks more often)
-    const bool roll = rollback_on();
+    choose_optimism();
+    bool roll = rollback_on();
     if (roll && !snap_.valid) take_snapshot();         // (the state as the caller left it: set_state / aztot_forces / the first call)
     int left = nsteps;
     while (left > 0)
@@ -1318,6 +1341,9 @@ void Engine::step(int nsteps)
                     sync();
                     if (!adapt_sort_interval()) throw std::runtime_error("lazy re-sort: a skin violation in a run that rebuilds its cells every step");
                 }
+                if (safeLooks_ > 0) safeLooks_--;
+                choose_optimism();
+                roll = rollback_on();
                 if (roll) take_snapshot();
                 sinceLook_ = 0;
                 lazyWindow_ = std::min(windowCap, 2 * lazyWindow_);
@@ -1344,9 +1370,14 @@ void Engine::step(int nsteps)
         }
         if (2 * sinceLook_ >= lazyWindow_) lazyWindow_ = std::min(windowCap, 2 * lazyWindow_);      // (this look stands in for the one that was due)
         sinceLook_ = 0;
-        if (roll) take_snapshot();
+        if (safeLooks_ > 0) safeLooks_--;
     }
     prepare_next_call();
+    if (lazyOn_)
+    {   // (behind prepare_next_call: it may have recorded the engine's first lists and knows whether every cell got one)
+        choose_optimism();
+        if (rollback_on()) take_snapshot(); else snap_.valid = false;
+    }
 }
 
 // steps per graph: one sort interval; with the cells rebuilt every step the sort ping-pongs the buffers, so it takes two steps to come back
@@ -1450,11 +1481,13 @@ void Engine::run_steps(int nsteps)
 // Records of k_pair_list's LDS tile for cells of at most maxT candidates.  LDS per wave bounds the kernel's occupancy and the hardware hands LDS out in
 // blocks of 1 280 B (gfx950: 160 KiB in 128 blocks), so the tile is the largest one that costs no more blocks than the smallest one that would do
 // (largest cell + 1 % + 1): C4's largest tile of 305 candidates gives 319 records in six blocks - 21 waves per CU by LDS - where "largest + 4 % + 6" took seven.
-static int tile_records_for(const StepParams& P, const PairLists& base, int maxT, int candCap)
+static int tile_records_for(const StepParams& P, const PairLists& base, int maxT, int candCap, bool roomy)
 {
     constexpr size_t kLdsBlock = 1280;
     PairLists L = base;
-    const int need = std::max(4 * kWave, std::min(candCap, maxT + maxT / 100 + 1));
+    // (roomy: systems that run without the clean-up launch - a cell that outgrows the tile there costs a window of steps run again, and LDS per wave is not
+    //  what bounds a step of a few thousand cells: + 6 %)
+    const int need = std::max(4 * kWave, std::min(candCap, roomy ? maxT + maxT / 16 + 4 : maxT + maxT / 100 + 1));
     L.candLds = need;
     const size_t blocks = (pair_list_lds_bytes(P, L) + kLdsBlock - 1) / kLdsBlock;
     int best = need;
@@ -1486,7 +1519,7 @@ void Engine::prepare_next_call()
             // every look) - the next call then walks them at full occupancy
             if (nl[5] == 0 && nl[6] == 0 && nl[3] > 0 && !(debug_ & 65536))
             {
-                const int candLds = tile_records_for(P_, pl, nl[3], candCap_);
+                const int candLds = tile_records_for(P_, pl, nl[3], candCap_, nranks_ == 1 && capacity_ <= 2 * kFuseKickMaxAtoms);
                 const int iterLds = std::max(2 * kListMinIter, std::min(iterCap_, (nl[4] + nl[4] / 8 + 2 + 7) & ~7));
                 if (candLds < candLds_ || iterLds < iterLds_) { candLds_ = std::min(candLds_, candLds); iterLds_ = std::min(iterLds_, iterLds); destroy_graphs(); graphCycle_ = 0; }
             }
@@ -1531,6 +1564,7 @@ bool Engine::adapt_sort_interval()
             std::fprintf(stderr, "aztot: per cell: %.2f list iterations, %.1f candidates, %.2f atoms\n", (double)nl[8] / nl[1], (double)nl[9] / nl[1], (double)nl[10] / nl[1]);
             HIP_CHECK(hipMemset(dNoList_ + 8, 0, sizeof(int32_t) * 3));
         }
+        if (nl[1] > 0) unlistedAtLook_ = nl[0] > 0;      // (nothing recorded since the last look: what that look found still stands)
         if (nl[1] > 0)
         {
             HIP_CHECK(hipMemsetAsync(dNoList_, 0, sizeof(int32_t) * 2, stream_));          // ([2] stays: it describes the lists in force; [3], [4] are all-time maxima)
@@ -1541,7 +1575,7 @@ bool Engine::adapt_sort_interval()
             // LDS per wave is what bounds the occupancy of k_pair_list: the tiles are sized from the largest cell ever recorded (+ 6 %), not from the
             // capacity of the arrays.  A cell that does not fit next time keeps no list for one interval (exact: the clean-up launch serves it) and is
             // counted; then the tiles grow again.
-            int candLds = tile_records_for(P_, pair_lists(), nl[3], candCap_);
+            int candLds = tile_records_for(P_, pair_lists(), nl[3], candCap_, nranks_ == 1 && capacity_ <= 2 * kFuseKickMaxAtoms);
             int iterLds = std::max(2 * kListMinIter, std::min(iterCap_, (nl[4] + nl[4] / 8 + 2 + 7) & ~7));
             if (nl[5] > 0) candLds = std::min(candCap_, std::max(candLds, candLds_ + 32));
             if (nl[6] > 0) iterLds = std::min(iterCap_, std::max(iterLds, iterLds_ + 8));
@@ -1618,6 +1652,8 @@ bool Engine::adapt_sort_interval()
     if (rebuildNeeded) { sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false; }
     lazyMeasured_ = true;
     int K = lazyK_;
+    // one GPU without the clean-up launch: a violation, or a cell that kept no list, means the steps since the last look were not exact
+    const bool goBack = optimistic_ && (c.lazyViolatedEver != 0 || unlistedAtLook_);
     if (debug_ & 8192)
     {   // debug: fixed interval whatever the speeds (exercises the wider-stencil fallback); violations are only counted
         if (c.lazyViolatedEver)
@@ -1658,7 +1694,7 @@ bool Engine::adapt_sort_interval()
         else if (fromSpeed > 0) K = fromSpeed;
     }
     if (K != lazyK_) { lazyK_ = K; destroy_graphs(); graphCycle_ = 0; }
-    return true;
+    return !goBack;
 }
 
 void Engine::check_overflow()

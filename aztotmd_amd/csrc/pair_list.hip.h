@@ -103,7 +103,7 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
     const int4 mx = ((const int4*)L.meta)[cell];
     asm volatile("" ::: "memory");                                  // (what follows is issued behind the loads above, not in front of them)
     // after a slack violation (one GPU) the clean-up launch stages every cell with the wider stencil: stand down
-    const bool violated = P.nranks == 1 && slack_violated(P, counts);
+    const bool violated = P.nranks == 1 && !P.optimistic && slack_violated(P, counts);
     int meta = mx.x;
     if (violated || cr >= nCellsRun || !list_usable(L, meta)) meta = -1;         // (a cell that does not walk its list is served by the clean-up launch)
     if (meta > 0)
