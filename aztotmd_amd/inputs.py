@@ -258,6 +258,8 @@ def config(name):
     if name == "C4L":     # the C4 liquid on a lattice of 64^3 cells (1 048 576 atoms): with cells of 9.176 A (--cell-size) the box is 40 cell layers = 8 ranks x 5 layers = 8 x 8
                           # lattice cells, so ONE emulated rank of 8 that exchanges its halo with itself (bench.py --emulate-ranks 8) sees a physical seam
         return lj_case((64, 64, 64), seed=20240508)
+    if name == "C4LT":    # C4L thermalised at 85 K: what a slab rank of 8 costs when its atoms move (its sort interval is then a third of the cold lattice's)
+        return lj_case((64, 64, 64), seed=20240508, vel_T=85.0)
     if name == "C1":      # synthetic twin of 'case study 1': 40 000 Ar gas atoms in a 1141.5 A box, LJ rc 4 A, cell_list 85 A, radiative thermostat
         rng = np.random.Generator(np.random.PCG64(20240506))
         N, L = 40000, 1141.5

@@ -110,6 +110,7 @@ REBUILD_ONLY = ("integrate1_bin", "bin", "scan_cells", "place", "rank_gather", "
 WORKLOADS = {"C4": "1 000 188 Ar, LJ rc 8.5 A, FCC 63^3 a=5.735 jitter 0.15, dt 1 fs, NVE, init_vel zero (BASELINE config '1 000 000 Ar LJ', SURVEY C4)",
              "C4T": "C4 thermalised: Maxwell velocities at 85 K (init_vel gaus), equilibrates to ~44 K kinetic + lattice potential",
              "C4X": "C4's lattice in a box of exactly 42 x 8.5 A (no overhang of the cells over the cut-off)",
+             "C4L": "the C4 liquid on a 64^3-cell lattice (1 048 576 atoms; with --cell-size 9.176: 40 cell layers = 8 ranks x 5)", "C4LT": "C4L thermalised: Maxwell velocities at 85 K",
              "C3": "1 000 188 atoms, LJ rc 8.5 A + Fennell/DSF Coulomb q=+-0.2 (SURVEY C3)",
              "C3T": "C3 thermalised: Maxwell velocities at 85 K",
              "C2": "40 000 Ar, LJ rc 8.5 A (SURVEY C2)", "C2T": "C2 thermalised: Maxwell velocities at 85 K",

@@ -1,6 +1,6 @@
-# every workload of DESIGN.md section 5 on the build in the tree: gpurun_out/r03/final_<name>.json
-mkdir -p gpurun_out/r03
-b() { name=$1; shift; AZTOT_VERBOSE=1 timeout -k 10 400 python bench.py "$@" > gpurun_out/r03/final_$name.json 2> gpurun_out/r03/final_$name.err; echo "== $name rc=$?"; python tools/bench_summary.py gpurun_out/r03/final_$name.json > gpurun_out/r03/final_$name.txt; head -2 gpurun_out/r03/final_$name.txt; grep "aztot: lists recorded" gpurun_out/r03/final_$name.err | tail -1; }
+# every workload of DESIGN.md section 5 on the build in the tree: gpurun_out/r03c/final_<name>.json
+mkdir -p gpurun_out/r03c
+b() { name=$1; shift; AZTOT_VERBOSE=1 timeout -k 10 400 python bench.py "$@" > gpurun_out/r03c/final_$name.json 2> gpurun_out/r03c/final_$name.err; echo "== $name rc=$?"; python tools/bench_summary.py gpurun_out/r03c/final_$name.json > gpurun_out/r03c/final_$name.txt; head -2 gpurun_out/r03c/final_$name.txt; grep "aztot: lists recorded" gpurun_out/r03c/final_$name.err | tail -1; }
 b C4 --workload C4
 b C4_driver --workload C4 --steps 20 --warmup 5
 b C4_long --workload C4 --steps 1000 --warmup 1000 --no-cpu-baseline
@@ -19,5 +19,5 @@ b S40 --workload S40 --steps 200 --warmup 200 --no-cpu-baseline
 b M4 --workload M4 --steps 100 --warmup 100 --no-cpu-baseline
 b B3 --workload B3 --steps 200 --warmup 200 --no-cpu-baseline
 b E2 --workload E2 --steps 100 --warmup 100 --no-cpu-baseline
-for k in 1 2; do AZTOT_VERBOSE=1 timeout -k 10 300 python bench.py --case-study $k --steps 1000 --warmup 1000 > gpurun_out/r03/final_CS$k.json 2> gpurun_out/r03/final_CS$k.err; echo "== CS$k rc=$?"; python tools/bench_summary.py gpurun_out/r03/final_CS$k.json | head -2; done
+for k in 1 2; do AZTOT_VERBOSE=1 timeout -k 10 300 python bench.py --case-study $k --steps 1000 --warmup 1000 > gpurun_out/r03c/final_CS$k.json 2> gpurun_out/r03c/final_CS$k.err; echo "== CS$k rc=$?"; python tools/bench_summary.py gpurun_out/r03c/final_CS$k.json | head -2; done
 b C4L --workload C4L --cell-size 9.176 --steps 500 --warmup 500 --no-cpu-baseline
