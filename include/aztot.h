@@ -170,7 +170,7 @@ typedef struct
     double engCoulRec, engCoulConst; /* Ewald sum: reciprocal part (engElec2, elec.cpp:333 ; cudaMD::engCoul2) and constant part
                                         (engElec1, ewald_const elec.cpp:144 ; engCoul3); engCoul above is the real-space part */
     int64_t sort_interval;       /* steps between two rebuilds of the cell list that the next aztot_step call will use (1: every step) */
-    int64_t sort_violations;     /* calls so far in which an atom left its cell's slack before the scheduled rebuild (handled exactly, by a wider stencil) */
+    int64_t sort_violations;     /* calls so far in which an atom left its cell's slack before the scheduled rebuild (handled exactly: by a wider stencil on one GPU, by running the steps since the last look again - from a device-side snapshot, cells rebuilt every step - on slab ranks and on small systems) */
     int64_t pair_lists;          /* 1: the steps between two rebuilds walk per-atom pair lists recorded at the rebuild (k_pair_list) ; 0: they stage every cell */
     int64_t cells_without_list;  /* cells that did not fit the lists at the last rebuild (more than 64 atoms, tile or list full): staged in full every step */
     int64_t rebuilds;            /* steps so far that rebuilt the cell list (clear_clist .. sort_atoms of main.cu:300-326; the reference: every step) */
