@@ -1072,3 +1072,38 @@ def test_pressure_from_wall_momentum():
     assert len(set(seen)) == 3          # a new window every time
     e.step(7)
     assert e.stats()["pressure"] == seen[-1]          # inside a window the last value stands (the reference prints it every `stat` steps only)
+
+
+@pytest.mark.parametrize("kind", ["lj", "radi", "fennell"])
+def test_window_run_again_without_the_cleanup_launch_is_exact(kind):
+    """Small systems on one GPU run their plain steps WITHOUT the clean-up launch behind k_pair_list (Engine::choose_optimism); a look that finds a skin violation
+    (or a cell that kept no list) goes back to the snapshot the last clean look left and runs the window again with the launch in place.  Debug bit 8192 holds the
+    interval at 32 steps on atoms far too fast for it, so windows ARE run again - and the result must be what an engine that launches the clean-up kernel behind
+    every step (debug bit 4) arrives at: the same trajectory (positions, velocities, forces, the radiative thermostat's per-atom energy and radius), the same
+    energies, wall counters and per-species crossings, to summation order (the repaired steps are the same kernels in both engines); and both equal the
+    every-step schedule to 1e-9.  'radi': the snapshot has to carry the thermostat's state and the step number its random numbers are keyed by."""
+    if kind == "radi":
+        case = inputs.lj_case((7, 7, 7), a=5.4, seed=61, rc=6.5, cell_list=6.9, T=3000.0, tstat="radi", vel_T=6000.0, radii=[(2.73, 4.731, 0.2)])
+    elif kind == "fennell":
+        case = inputs.lj_case((7, 7, 7), a=5.4, seed=62, rc=6.5, cell_list=6.9, charges=(0.2, -0.2), elec="fenn", r_real=6.5, vel_T=9000.0)
+    else:
+        case = inputs.lj_case((7, 7, 7), a=5.4, seed=23, rc=6.5, cell_list=6.9, vel_T=9000.0)
+    case["dt"] = 0.002
+    a = engine(case, sort_every=32, debug=8192)
+    b = engine(case, sort_every=32, debug=8192 | 4)
+    c = engine(case, sort_every=1)
+    for n in (3, 40, 9, 70, 33):               # (an engine's first two looks are spent with the launch in place: the later calls are the ones that run without it)
+        a.step(n); b.step(n); c.step(n)
+    sa, sb, sc, sta, stb, stc = a.state(), b.state(), c.state(), a.stats(), b.stats(), c.stats()
+    assert sta["sort_violations"] > 0 and stb["sort_violations"] > 0
+    keys = ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz") + (("U", "radius") if kind == "radi" else ())
+    for k in keys:
+        assert rel_err(sa[k], sb[k]) < 1e-11, (k, rel_err(sa[k], sb[k]))
+        assert rel_err(sa[k], sc[k]) < 1e-9, (k, rel_err(sa[k], sc[k]))
+    assert sta["negCross"] == stb["negCross"] == stc["negCross"] and sta["posCross"] == stb["posCross"] == stc["posCross"]
+    assert np.array_equal(a.species_crossings(), b.species_crossings()) and np.array_equal(a.species_crossings(), c.species_crossings())
+    for k in ("engVdW", "engKin", "engTot", "engCoul", "engTemp"):
+        if abs(stc[k]) > 0:
+            assert abs(sta[k] - stb[k]) <= 1e-11 * abs(stb[k]), (k, sta[k], stb[k])
+            assert abs(sta[k] - stc[k]) <= 1e-9 * abs(stc[k]), (k, sta[k], stc[k])
+    assert sta["step"] == stb["step"] == stc["step"] == 155
