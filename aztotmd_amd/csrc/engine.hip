@@ -1265,14 +1265,15 @@ void Engine::take_snapshot()
         snap_.partials = (double*)alloc(sizeof(double) * (size_t)PS_COUNT * maxBlocks_);
     }
     const AtomArrays& A = cur();
+    StateCopy C;
     const double* src[] = {A.x, A.y, A.z, A.vx, A.vy, A.vz, A.fx, A.fy, A.fz, A.U, A.rad};
     double* dst[] = {snap_.A.x, snap_.A.y, snap_.A.z, snap_.A.vx, snap_.A.vy, snap_.A.vz, snap_.A.fx, snap_.A.fy, snap_.A.fz, snap_.A.U, snap_.A.rad};
-    for (int k = 0; k < 11; k++) HIP_CHECK(hipMemcpyAsync(dst[k], src[k], nd, hipMemcpyDeviceToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(snap_.A.type, A.type, ni, hipMemcpyDeviceToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(snap_.A.id, A.id, ni, hipMemcpyDeviceToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(snap_.stats, dStats_, sizeof(DevStats), hipMemcpyDeviceToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(snap_.counts, dCounts_, sizeof(Counts), hipMemcpyDeviceToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(snap_.partials, dPartials_, sizeof(double) * (size_t)PS_COUNT * maxBlocks_, hipMemcpyDeviceToDevice, stream_));
+    for (int k = 0; k < 11; k++) { C.srcD[k] = src[k]; C.dstD[k] = dst[k]; }
+    C.srcI[0] = A.type; C.dstI[0] = snap_.A.type; C.srcI[1] = A.id; C.dstI[1] = snap_.A.id;
+    C.srcP = dPartials_; C.dstP = snap_.partials; C.nP = (long long)PS_COUNT * maxBlocks_;
+    C.srcS[0] = (const int32_t*)dStats_; C.dstS[0] = (int32_t*)snap_.stats; C.nS[0] = (int)(sizeof(DevStats) / 4);
+    C.srcS[1] = (const int32_t*)dCounts_; C.dstS[1] = (int32_t*)snap_.counts; C.nS[1] = (int)(sizeof(Counts) / 4);
+    hipLaunchKernelGGL(k_copy_state, dim3(div_up(capacity_, kBlock)), dim3(kBlock), 0, stream_, C, capacity_);
     snap_.buf = buf_state();
     snap_.valid = true;
     stepsSinceSnap_ = 0;
@@ -1285,16 +1286,16 @@ void Engine::replay_from_snapshot()
     sync();
     destroy_graphs(); graphCycle_ = 0;
     set_buf_state(snap_.buf);
-    const size_t nd = sizeof(double) * (size_t)capacity_, ni = sizeof(int32_t) * (size_t)capacity_;
     const AtomArrays& A = cur();
+    StateCopy C;
     double* dst[] = {A.x, A.y, A.z, A.vx, A.vy, A.vz, A.fx, A.fy, A.fz, A.U, A.rad};
     const double* src[] = {snap_.A.x, snap_.A.y, snap_.A.z, snap_.A.vx, snap_.A.vy, snap_.A.vz, snap_.A.fx, snap_.A.fy, snap_.A.fz, snap_.A.U, snap_.A.rad};
-    for (int k = 0; k < 11; k++) HIP_CHECK(hipMemcpyAsync(dst[k], src[k], nd, hipMemcpyDeviceToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(A.type, snap_.A.type, ni, hipMemcpyDeviceToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(A.id, snap_.A.id, ni, hipMemcpyDeviceToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(dStats_, snap_.stats, sizeof(DevStats), hipMemcpyDeviceToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(dCounts_, snap_.counts, sizeof(Counts), hipMemcpyDeviceToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(dPartials_, snap_.partials, sizeof(double) * (size_t)PS_COUNT * maxBlocks_, hipMemcpyDeviceToDevice, stream_));
+    for (int k = 0; k < 11; k++) { C.srcD[k] = src[k]; C.dstD[k] = dst[k]; }
+    C.srcI[0] = snap_.A.type; C.dstI[0] = A.type; C.srcI[1] = snap_.A.id; C.dstI[1] = A.id;
+    C.srcP = snap_.partials; C.dstP = dPartials_; C.nP = (long long)PS_COUNT * maxBlocks_;
+    C.srcS[0] = (const int32_t*)snap_.stats; C.dstS[0] = (int32_t*)dStats_; C.nS[0] = (int)(sizeof(DevStats) / 4);
+    C.srcS[1] = (const int32_t*)snap_.counts; C.dstS[1] = (int32_t*)dCounts_; C.nS[1] = (int)(sizeof(Counts) / 4);
+    hipLaunchKernelGGL(k_copy_state, dim3(div_up(capacity_, kBlock)), dim3(kBlock), 0, stream_, C, capacity_);
     sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false; preIntegrated_ = false; haloInfoPending_ = false; unlistedState_ = 0;
     kickOwed_ = false;
     if (nranks_ > 1) { if (lazyK_ != 1) lazyK_ = 1; }

@@ -601,6 +601,30 @@ __global__ __launch_bounds__(kBlock) void k_integrate_plain2(StepParams P, SpecT
         }
 }
 
+// The dynamic state in one launch (Engine::take_snapshot / replay_from_snapshot: sixteen separate copies cost a short aztot_step call more host time than its
+// steps): eleven arrays of doubles and two of 32-bit integers of `n` elements each, the partial sums, DevStats and Counts.
+struct StateCopy
+{
+    const double* srcD[11]; double* dstD[11];
+    const int32_t* srcI[2]; int32_t* dstI[2];
+    const double* srcP; double* dstP; long long nP;            // partial sums
+    const int32_t* srcS[2]; int32_t* dstS[2]; int nS[2];       // DevStats, Counts as 32-bit words
+};
+__global__ __launch_bounds__(kBlock) void k_copy_state(StateCopy C, int n)
+{
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t < n)
+    {
+#pragma unroll
+        for (int k = 0; k < 11; k++) C.dstD[k][t] = C.srcD[k][t];
+        C.dstI[0][t] = C.srcI[0][t]; C.dstI[1][t] = C.srcI[1][t];
+    }
+    for (long long q = t; q < C.nP; q += (long long)gridDim.x * kBlock) C.dstP[q] = C.srcP[q];
+    if (blockIdx.x == 0)
+        for (int k = 0; k < 2; k++)
+            for (int q = threadIdx.x; q < C.nS[k]; q += kBlock) C.dstS[k][q] = C.srcS[k][q];
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: exclusive prefix sum of the cell histogram (calc_firstAtomInCell cuSort.cu:130-143 is ONE thread).
 //   k_scan_totals : each workgroup sums its chunk of kScanChunk cells
