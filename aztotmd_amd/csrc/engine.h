@@ -93,6 +93,8 @@ private:
     void sort_and_forces(int stepMode, bool withBonded = true);   // 0: bin + sort + forces (aztot_forces), 1: a step that re-sorts, 2: a plain step of the lazy re-sort
     void launch_step_kernels();
     bool adapt_sort_interval();
+    void look_sync();               // what a look reads (Counts, the list builder's report) copied into pinned memory behind the queued work, then ONE stream synchronisation
+    void* hLook_ = nullptr;         // pinned: Counts followed by 16 ints of PairLists::noList
     void run_steps(int nsteps);
     void launch_pair();
     int pair_variant() const;

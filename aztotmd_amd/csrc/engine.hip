@@ -368,6 +368,8 @@ void Engine::release()
     evHaloInfo_ = nullptr;
     if (hHalo_) (void)hipHostFree(hHalo_);
     hHalo_ = nullptr;
+    if (hLook_) (void)hipHostFree(hLook_);
+    hLook_ = nullptr;
     if (commStream_) { (void)hipStreamSynchronize(commStream_); (void)hipStreamDestroy(commStream_); }
     commStream_ = nullptr;
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -1335,11 +1337,11 @@ void Engine::step(int nsteps)
         {
             if (2 * left > lazyWindow_)
             {
-                sync();
+                look_sync();
                 if (!adapt_sort_interval())
                 {   // (slab ranks, all together) an atom left its slack somewhere since the snapshot: those steps again, exactly, then a look that cannot fail
                     replay_from_snapshot();
-                    sync();
+                    look_sync();
                     if (!adapt_sort_interval()) throw std::runtime_error("lazy re-sort: a skin violation in a run that rebuilds its cells every step");
                 }
                 if (safeLooks_ > 0) safeLooks_--;
@@ -1355,7 +1357,7 @@ void Engine::step(int nsteps)
     kickOwed_ = lazyKick_;          // set here, not in launch_step_kernels: a replayed graph does not pass through the host code
     finish_steps();
     check_launch("step kernels");
-    sync();
+    look_sync();
     check_overflow();
     if (lazyOn_)
     {
@@ -1365,7 +1367,7 @@ void Engine::step(int nsteps)
             kickOwed_ = lazyKick_;
             finish_steps();
             check_launch("step kernels (run again)");
-            sync();
+            look_sync();
             check_overflow();
             if (!adapt_sort_interval()) throw std::runtime_error("lazy re-sort: a skin violation in a run that rebuilds its cells every step");
         }
@@ -1550,16 +1552,30 @@ void Engine::prepare_next_call()
 // slack C4 ran at K = 16, with two thirds at K = 24-28, no violation in 2 000 steps; every violation widens the margin for good - a system that heats up,
 // like the Born-Mayer-Huggins melt B3, would otherwise run into one after the other) - half on slab ranks, whose repair (a window of steps run again) is dearer.
 // Returns false when the slab ranks have found a violation: the caller takes every rank back to its snapshot
+// A look needs the device's Counts and the list builder's report.  Two blocking copies behind a stream synchronisation were three round trips between host
+// and device (~40 us of a short aztot_step call); queued into pinned memory BEFORE the synchronisation they ride on it (a small kernel writing the pinned block directly: measured, the same).
+void Engine::look_sync()
+{
+    if (lazyOn_)
+    {
+        if (!hLook_) HIP_CHECK(hipHostMalloc(&hLook_, sizeof(Counts) + sizeof(int32_t) * 16, hipHostMallocDefault));
+        HIP_CHECK(hipMemcpyAsync(hLook_, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost, stream_));
+        if (listsOn_ && dNoList_) HIP_CHECK(hipMemcpyAsync((char*)hLook_ + sizeof(Counts), dNoList_, sizeof(int32_t) * 16, hipMemcpyDeviceToHost, stream_));
+    }
+    sync();
+}
+
+// (called right behind look_sync: reads what it left in pinned memory)
 bool Engine::adapt_sort_interval()
 {
     Counts c;
-    HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
+    std::memcpy(&c, hLook_, sizeof(Counts));
     bool rebuildNeeded = false;                    // this rank's lists were re-allocated: the next step must rebuild (on every rank: rebuild steps carry the full exchange)
     if (listsOn_)
     {   // cells that keep no list are staged by the small clean-up launch: fine for a few, slow for many (stencils wider than one tile, cells of more than
         // 64 atoms) - then the plain steps go back to staging every cell
         int32_t nl[16];
-        HIP_CHECK(hipMemcpy(nl, dNoList_, sizeof(nl), hipMemcpyDeviceToHost));
+        std::memcpy(nl, (const char*)hLook_ + sizeof(Counts), sizeof(nl));
         if ((debug_ & 2097152) && nl[1] > 0)
         {   // measurement aid: mean list length / tile size / atoms per cell over the cells recorded since the last look
             std::fprintf(stderr, "aztot: per cell: %.2f list iterations, %.1f candidates, %.2f atoms\n", (double)nl[8] / nl[1], (double)nl[9] / nl[1], (double)nl[10] / nl[1]);
