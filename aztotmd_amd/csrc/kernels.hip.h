@@ -1247,15 +1247,25 @@ __global__ __launch_bounds__(256) void k_collect(double* __restrict__ partials, 
 // Works on this rank's sums; the cross-rank sum is taken when the host asks for statistics (Engine::get_stats).
 __global__ void k_finalize(StepParams P, DevStats* st, const double* __restrict__ stage, unsigned slotMask)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int slot = 0; slot < PS_COUNT; slot++)
+    // one lane per slot adds the slot's sub-totals in their fixed order (the loads of all slots travel together: one thread walking 20 x 16 of them in turn took
+    // 13 us at the end of every aztot_step call); lane 0 then does the bookkeeping
+    __shared__ double sums[PS_COUNT];
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x < PS_COUNT)
+    {
+        const int slot = threadIdx.x;
+        double v;
         if ((slotMask >> slot) & 1u)
         {
-            double v = 0.0;
+            v = 0.0;
             for (int k = 0; k < kCollectParts; k++) v += stage[slot * kCollectParts + k];
             st->local[slot] = v;
         }
-    const double* sums = st->local;
+        else v = st->local[slot];
+        sums[slot] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     st->engElecField = sums[PS_EFIELD];
     st->engVdW = sums[PS_EVDW];
     st->engCoul = sums[PS_ECOUL];
