@@ -189,6 +189,12 @@ private:
     bool thermoTouched_ = false;    // the caller set U / radius on a run whose model does not use them: keep them attached to their atoms
     bool lazyKick_ = false;         // large plain-NVE runs: integrate2 is folded into the next step's integrate1 (flushed by finish_steps)
     bool kickOwed_ = false;
+    // Equilibration rescaling (control.txt: nequil / eqfreq) acts on a handful of steps only - step numbers the host can tell (hostStep_ mirrors DevStats::step) -,
+    // so only those steps take the path that sums the kinetic energy on the device, decides a factor and scales; every other step of a thermostat run takes the
+    // short path of a run without equilibration (case study 2: 6 launches per step -> 2)
+    long long hostStep_ = 0;        // steps launched so far (== DevStats::step once the stream has drained)
+    bool lastStepEquil_ = false;    // the last step launched left its kinetic energy in DevStats::local (k_reduce_kin), not in the partial sums
+    bool equil_phase() const { return P_.nEq > 0 && hostStep_ < P_.nEq; }
     bool fuseEpilogue_ = false;     // small plain-NVE runs: the tile kernel's epilogue applies integrate2
     bool fuseNow_ = false;          // the pair launch in flight also does integrate2's job (plain NVE steps, tile kernel)
     bool ekinFromPair_ = false;     // where the last step left its kinetic-energy partials
@@ -248,6 +254,7 @@ private:
         void *stats = nullptr, *counts = nullptr;
         double* partials = nullptr;
         BufState buf{};
+        long long hostStep = 0;
         bool valid = false;
     } snap_;
     long long stepsSinceSnap_ = 0;

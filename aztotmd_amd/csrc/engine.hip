@@ -1156,7 +1156,12 @@ void Engine::launch_step_kernels()
 {
     const int gridAtoms = div_up(capacity_, kBlock);
     if (P_.tstat == AZTOT_TSTAT_NOSE) timed("nose_begin", [&] { hipLaunchKernelGGL(k_nose_begin, dim3(1), dim3(64), 0, stream_, P_, dStats_); });
-    const bool equil = P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE;     // the step needs the all-atom kinetic energy on the device
+    // does this step need the all-atom kinetic energy on the device?  Nose-Hoover: every step; equilibration rescaling: the steps it acts on
+    // (integrators.cpp:511-522: step <= nequil and a multiple of eqfreq) - the host knows the number of the step it is launching.  (A captured cycle is
+    // replayed at many step numbers: cycles are captured only once the equilibration period is over, can_graph.)
+    const long long iStep = hostStep_ + 1;
+    const bool scalingDue = !capturing_ && P_.nEq > 0 && iStep <= P_.nEq && P_.freqEq > 0 && (iStep % P_.freqEq) == 0;
+    const bool equil = scalingDue || P_.tstat == AZTOT_TSTAT_NOSE;
     // plain NVE steps leave integrate2 to somebody else (decided once, in the constructor): small systems / slabs -> the tile
     // kernel's epilogue (fuseEpilogue_); large ones -> the next step's k_integrate1_bin (lazyKick_, see finish_steps)
     fuseNow_ = fuseEpilogue_;
@@ -1216,6 +1221,13 @@ void Engine::launch_step_kernels()
             hipLaunchKernelGGL(k_post, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dStats_, dPhotons_, dUvx_, dUvy_, dUvz_,
                                dPartials_, maxBlocks_);
         });
+    if (scalingDue && P_.tstat != AZTOT_TSTAT_NOSE)
+    {   // the factor has been applied: the steps that follow take the short path, which never decides one (DevStats::vscale is read by every thermostat kernel)
+        static const double one = 1.0;
+        HIP_CHECK(hipMemcpyAsync(&dStats_->vscale, &one, sizeof(double), hipMemcpyHostToDevice, stream_));
+    }
+    lastStepEquil_ = equil;
+    if (!capturing_) hostStep_++;
 }
 
 // the per-block partial sums are folded into the statistics only when somebody can look at them: at the end of a
@@ -1231,7 +1243,7 @@ void Engine::finish_steps()
         kickOwed_ = false;
     }
     unsigned mask = (1u << PS_COUNT) - 1u;
-    if (P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_NOSE) mask &= ~(1u << PS_EKIN);   // k_reduce_kin / k_scale_decision own engKin then
+    if (lastStepEquil_) mask &= ~(1u << PS_EKIN);   // k_reduce_kin / k_scale_decision own engKin then
     if (!(P_.nEq > 0 || P_.tstat == AZTOT_TSTAT_RADI)) mask &= ~(1u << PS_ETEMP);
     if (!hasBonded_) mask &= ~((1u << PS_EBOND) | (1u << PS_EANGLE));
     collect_and_finalize(mask);
@@ -1277,6 +1289,7 @@ void Engine::take_snapshot()
     C.srcS[1] = (const int32_t*)dCounts_; C.dstS[1] = (int32_t*)snap_.counts; C.nS[1] = (int)(sizeof(Counts) / 4);
     hipLaunchKernelGGL(k_copy_state, dim3(div_up(capacity_, kBlock)), dim3(kBlock), 0, stream_, C, capacity_);
     snap_.buf = buf_state();
+    snap_.hostStep = hostStep_;
     snap_.valid = true;
     stepsSinceSnap_ = 0;
 }
@@ -1300,6 +1313,7 @@ void Engine::replay_from_snapshot()
     hipLaunchKernelGGL(k_copy_state, dim3(div_up(capacity_, kBlock)), dim3(kBlock), 0, stream_, C, capacity_);
     sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false; preIntegrated_ = false; haloInfoPending_ = false; unlistedState_ = 0;
     kickOwed_ = false;
+    hostStep_ = snap_.hostStep;
     if (nranks_ > 1) { if (lazyK_ != 1) lazyK_ = 1; }
     else
     {   // one GPU: the same steps with the clean-up launch behind every k_pair_list (it stages the cells without a list and, from the step of a violation
@@ -1398,7 +1412,7 @@ bool Engine::can_graph() const
     // launches to keep the GPU busy, and each hipGraphLaunch costs a 40 us bubble in front of its first kernel (rocprofv3 kernel trace): 0.1594 ms/step
     // replayed, 0.1575 launched one by one; 40 000 atoms: 0.0184 replayed, 0.0187 one by one.  (Debug bit 8388608: replay whatever the size.)
     const bool worthIt = capacity_ <= 2 * kFuseKickMaxAtoms || (debug_ & 8388608);
-    return opt_.use_graph && worthIt && (nranks_ == 1 || slabGraph) && !profile_;
+    return opt_.use_graph && worthIt && (nranks_ == 1 || slabGraph) && !profile_ && !equil_phase();
 }
 
 // the graph of one cycle of steps for the buffer state the engine is in (captured on first use; the capture executes nothing).  One graph per buffer
@@ -1467,6 +1481,7 @@ void Engine::run_steps(int nsteps)
             GraphSlot* slot = graph_for_state(cycle);
             HIP_CHECK(hipGraphLaunch(slot->exec, stream_));
             done += cycle;
+            hostStep_ += cycle;
             rebuilds_ += (lazyOn_ && lazyK_ > 1) ? 1 : cycle;       // (a captured cycle: one sort interval, or two every-step steps)
             set_buf_state(slot->after);           // one sort per cycle (K > 1) and the coordinate-array swaps of the fused steps
             sinceSort_ = 1 << 30;                 // the next cycle (or the eager remainder) starts with a sort
@@ -1853,6 +1868,7 @@ void Engine::set_clock(const aztot_clock& in)
     s.pendingKick = 0;
     HIP_CHECK(hipMemcpy(dStats_, &s, sizeof(DevStats), hipMemcpyHostToDevice));
     lastPresStep_ = in.step;
+    hostStep_ = in.step;
     sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false;       // the next call rebuilds the cells
     destroy_graphs();
 }

@@ -1270,6 +1270,7 @@ __global__ void k_finalize(StepParams P, DevStats* st, const double* __restrict_
     st->engVdW = sums[PS_EVDW];
     st->engCoul = sums[PS_ECOUL];
     st->engKin = sums[PS_EKIN];
+    if ((slotMask >> PS_EKIN) & 1u) st->ekSim = sums[PS_EKIN];    // (steps that did not go through k_scale_decision: the reference's sim->engKin is the last integrate2's)
     st->engTemp = sums[PS_ETEMP];
     // running totals grow only by what THIS call collected: a slot outside slotMask still holds the previous call's window in
     // local[] (aztot_forces after aztot_step collects the energies only and must leave the wall counters alone)
