@@ -232,6 +232,8 @@ private:
     double* altXyz_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     bool fuseNextOk_ = false;       // this engine may fuse (decided once)
     bool fuseNext_ = false;         // the pair kernel of the step being launched fuses
+    bool fuseNextTstat_ = false;    // ... in a run with the radiative thermostat: the fused epilogue also applies it (k_pair_list<..., TSTAT>; decided once)
+    bool pairClosedStep_ = false;   // the pair launch of the step in flight has closed the step (second half-kick + thermostat): no k_integrate2_post / k_boundary_radi
     bool preIntegrated_ = false;    // the step being launched was opened by the previous step's pair kernel: no k_integrate1_bin
     int stepsLeftInRun_ = 0;        // steps that follow the one being launched before the host looks / the cycle ends
     // a sort interval may run on from one aztot_step call into the next (one GPU, pair lists): the lists recorded at the last rebuild are those of the

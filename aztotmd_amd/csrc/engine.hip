@@ -285,7 +285,14 @@ void Engine::construct()
         // pair lists; debug bit 131072 switches it off.  Up to ~500 000 atoms per GPU, where a step is bound by launch latency (measured: 40 000 atoms 0.0230 ->
         // 0.0199 ms/step; emulated slab ranks of 143 000 / 250 000 / 333 000 atoms -9 % / -5 % / -4 %): on 1 M atoms the 13-lane stores of the epilogue cost
         // the pair kernel exactly what the streaming k_integrate1_bin<2> costs on its own (111 + 31 -> 140 us); debug bit 262144 forces it on there
-        if (plainNve && listsOn_ && variant == 2 && !(debug_ & 131072) && (capacity_ <= 2 * kFuseKickMaxAtoms || (debug_ & 262144)))
+        // ... and runs with the radiative thermostat (case study 1: 40 000 atoms, two launches per step - the pair kernel and the boundary kernel that closes
+        // the step with the thermostat and opens the next): the thermostat acts on one atom at a time, so the lane that closes the atom's step applies it too
+        // (k_pair_list<..., TSTAT>) and a step is ONE launch.  Not where the pair kernel reads radii (the thermostat rewrites them while other waves still
+        // gather: case study 2's surk potential), not with bonded terms or the Ewald sum (their forces arrive after the pair kernel).
+        const bool radiFuse = P_.tstat == AZTOT_TSTAT_RADI && !hasBonded_ && !hasEwald_ && !(debug_ & 128) && !P_.use_radii && P_.pad1 != 4 && (P_.single_lj || P_.pad1 == 2) &&
+                              nranks_ == 1 && capacity_ <= 2 * kFuseKickMaxAtoms;
+        fuseNextTstat_ = radiFuse && listsOn_ && variant == 2 && !(debug_ & 131072);
+        if (((plainNve && (capacity_ <= 2 * kFuseKickMaxAtoms || (debug_ & 262144))) || radiFuse) && listsOn_ && variant == 2 && !(debug_ & 131072))
         {
             fuseNextOk_ = true;
             const size_t nd = sizeof(double) * (size_t)capacity_;
@@ -937,6 +944,7 @@ void Engine::launch_pair()
                 NextStep nx;
                 nx.st = dStats_; nx.cnt = dCounts_; nx.R0 = ref_;
                 if (fuseNext_) { nx.xn = altXyz_[cur_][0]; nx.yn = altXyz_[cur_][1]; nx.zn = altXyz_[cur_][2]; }
+                if (fuseNext_ && fuseNextTstat_) { nx.photons = dPhotons_; nx.uvx = dUvx_; nx.uvy = dUvy_; nx.uvz = dUvz_; pairClosedStep_ = true; }
                 else nx.pendingAfter = lazyKick_ ? 1 : -1;         // this step's second half-kick is owed to the next k_integrate1_bin (a call may open
                                                                     // with a plain step, where no scan re-arms the flag)
                 timed("pair_list", [&] { splitBlocks_ = launch_pair_list(Q, S_, dPots_, cur(), dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_, PairRange(), pl, nx, wantEnergies); });
@@ -1172,14 +1180,18 @@ void Engine::launch_step_kernels()
     {   // does this step's pair kernel also open the next step?  Only if this step walks the lists (k_pair_list and its clean-up launch carry the epilogue)
         const bool lists = listsOn_ && lazyOn_ && lazyK_ > 1 && pair_variant() == 2;
         fuseNext_ = fuseNextOk_ && lists && nextPlain;
+        // thermostat runs: only where no clean-up launch follows (it has no thermostat epilogue), on steps without equilibration scaling, never with energies on every step
+        if (fuseNextTstat_) fuseNext_ = fuseNext_ && optimistic_ && !equil && !(debug_ & DBG_ENERGIES_EVERY_STEP);
     }
+    pairClosedStep_ = false;
     sort_and_forces(stepMode);
     const bool fused = fuseNow_;                 // launch_pair drops the request if the tile kernel is not the one running
     fuseNow_ = false;
     ekinFromPair_ = fused;
     // radiative thermostat without equilibration scaling: nothing global happens between the second half-kick and the thermostat - one launch (debug bit
     // 4194304: two, as everywhere else)
-    const bool kickAndPost = !fused && !lazyKick_ && !equil && P_.tstat == AZTOT_TSTAT_RADI && !(debug_ & 4194304);
+    const bool closed = pairClosedStep_;           // (thermostat run, fused: the pair kernel has closed this step and opened the next)
+    const bool kickAndPost = !closed && !fused && !lazyKick_ && !equil && P_.tstat == AZTOT_TSTAT_RADI && !(debug_ & 4194304);
     // ... and when a plain step follows, the same launch opens it (k_boundary_radi; debug bit 33554432: no)
     if (kickAndPost && nextPlain && !(debug_ & 33554432))
     {
@@ -1196,7 +1208,7 @@ void Engine::launch_step_kernels()
             hipLaunchKernelGGL(k_integrate2_post, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal, dPartials_,
                                maxBlocks_, dStats_, dPhotons_, dUvx_, dUvy_, dUvz_);
         });
-    else if (!fused && !lazyKick_)
+    else if (!closed && !fused && !lazyKick_)
         timed("integrate2", [&] {
             hipLaunchKernelGGL(k_integrate2, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dCellCount_, P_.nCellLocal, dPartials_,
                                maxBlocks_, dStats_);
@@ -1216,7 +1228,7 @@ void Engine::launch_step_kernels()
         }
         timed("scale_decision", [&] { hipLaunchKernelGGL(k_scale_decision, dim3(1), dim3(64), 0, stream_, P_, dStats_, dEkGlobal_); });
     }
-    if ((equil || P_.tstat == AZTOT_TSTAT_RADI) && !kickAndPost)
+    if ((equil || P_.tstat == AZTOT_TSTAT_RADI) && !kickAndPost && !closed)
         timed("post_tstat", [&] {
             hipLaunchKernelGGL(k_post, dim3(gridAtoms), dim3(kBlock), 0, stream_, P_, S_, cur(), dCounts_, dStats_, dPhotons_, dUvx_, dUvy_, dUvz_,
                                dPartials_, maxBlocks_);

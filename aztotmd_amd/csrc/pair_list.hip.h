@@ -59,7 +59,9 @@ inline int pair_list_entry_scale(const StepParams& P) { return P.single_lj ? 24 
 // terms feed nothing else, the compiler drops them and their two wave reductions.
 // MULTI = false: one wave per cell, known when the kernel is compiled (the wave number and every multiple of W fold away: 585 -> 515 vector instructions per
 // cell on the 1 M-atom liquid); true: W = PairLists::waves waves share the cell's tile.
-template <int MODE, int VDW, bool ENG, bool MULTI>
+// TSTAT = true (launches that fuse the next step in a run with the radiative thermostat; never with ENG: the call's last step does not fuse): the epilogue
+// applies the thermostat between closing this step and opening the next, operation for operation what k_boundary_radi does in a launch of its own.
+template <int MODE, int VDW, bool ENG, bool MULTI, bool TSTAT = false>
 __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_list(StepParams P, SpecTable S, const DevPot* __restrict__ pots, AtomArrays A,
                                                      const int32_t* __restrict__ cellStart, int firstCell, int nCellsRun,
                                                      double* __restrict__ partials, int maxBlocks, const Counts* __restrict__ counts, int blockBase, PairLists L,
@@ -295,6 +297,8 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
                 const double rM = S.rMhdt[ti], m = S.mass[ti];
                 double vx = v0x + rM * fxi, vy = v0y + rM * fyi, vz = v0z + rM * fzi;
                 if (ENG && P.fuseKick) eK += (vx * vx + vy * vy + vz * vz) * m;     // (the kinetic energy too is looked at after a call's last step only)
+                if (TSTAT && N.xn)      // close the step as k_integrate2_post does: the thermostat acts on the fully kicked velocity; its draws are keyed by this step's number
+                    (void)post_tstat_atom(P, S, A, N.st, N.photons, N.uvx, N.uvy, N.uvz, myi, vx, vy, vz, N.st->stepAtSort + (long long)P.cycleStep);
                 if (N.xn) next_step_atom(P, S, N, myi, ti, xr, yr, zr, fxi, fyi, fzi, vx, vy, vz, r0x, r0y, r0z, nacc);
                 A.vx[myi] = vx; A.vy[myi] = vy; A.vz[myi] = vz;
             }
@@ -677,9 +681,15 @@ inline void launch_pair_list_as(const StepParams& P, const SpecTable& S, const D
 {
     const size_t lds = pair_list_lds_bytes(P, L);
     const dim3 grid(pair_range_grid(R.n)), block(kWave * L.waves);
-#define AZTOT_LAUNCH_LIST(E, M) hipLaunchKernelGGL((k_pair_list<MODE, VDW, E, M>), grid, block, lds, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt, R.blockBase, L, N)
-    if (L.waves == 1) { if (energies) AZTOT_LAUNCH_LIST(true, false); else AZTOT_LAUNCH_LIST(false, false); }
-    else { if (energies) AZTOT_LAUNCH_LIST(true, true); else AZTOT_LAUNCH_LIST(false, true); }
+#define AZTOT_LAUNCH_LIST(E, M, T) hipLaunchKernelGGL((k_pair_list<MODE, VDW, E, M, T>), grid, block, lds, stream, P, S, pots, A, cellStart, R.first, R.n, partials, maxBlocks, cnt, R.blockBase, L, N)
+    if (N.photons)
+    {   // thermostat-fused epilogue: modes that do not read radii (the thermostat rewrites them while other waves would still be gathering), never on a step
+        // whose energies are wanted (Engine::launch_step_kernels)
+        if (energies || MODE == 0 || MODE == 4) throw std::runtime_error("k_pair_list: the thermostat cannot be fused into this launch");
+        if (MODE != 0 && MODE != 4) { if (L.waves == 1) AZTOT_LAUNCH_LIST(false, false, (MODE != 0 && MODE != 4)); else AZTOT_LAUNCH_LIST(false, true, (MODE != 0 && MODE != 4)); }
+    }
+    else if (L.waves == 1) { if (energies) AZTOT_LAUNCH_LIST(true, false, false); else AZTOT_LAUNCH_LIST(false, false, false); }
+    else { if (energies) AZTOT_LAUNCH_LIST(true, true, false); else AZTOT_LAUNCH_LIST(false, true, false); }
 #undef AZTOT_LAUNCH_LIST
 }
 

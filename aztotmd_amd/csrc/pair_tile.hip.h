@@ -416,6 +416,9 @@ struct NextStep
     RefPos R0{};                                             // positions at the last rebuild
     DevStats* st = nullptr;
     Counts* cnt = nullptr;
+    // radiative thermostat (k_pair_list<..., TSTAT>): the fused epilogue closes the step the way k_integrate2_post does - second half-kick, then the thermostat
+    // (post_tstat_atom, keyed by the number of the step being closed) - before it opens the next one; nullptr: plain NVE
+    const double *photons = nullptr, *uvx = nullptr, *uvy = nullptr, *uvz = nullptr;
     int pendingAfter = -1;                                   // launches that do NOT fuse, in an engine that sometimes does: what k_pair_list leaves in DevStats::pendingKick
                                                              // (1: this step's second half-kick is owed to the next k_integrate1_bin / k_integrate2 ; -1: hands off)
 };

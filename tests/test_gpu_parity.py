@@ -702,9 +702,11 @@ def test_kick_and_radiative_thermostat_in_one_launch():
     Same operations in the same order: bit-identical to the two-launch form (debug bit 4194304) and to the form without the boundary kernel (33554432),
     per-atom internal energies and radii included, and equal to the oracle."""
     case = inputs.lj_case((8, 8, 8), a=5.6, seed=61, rc=7.5, cell_list=7.9, vel_T=60.0, T=60.0, tstat="radi", radii=[(2.73, 4.731, 0.2)])       # 5 cells per axis: the lazy re-sort engages
-    a = engine(case, pair_variant=2)
-    b = engine(case, pair_variant=2, debug=4194304)
-    c = engine(case, pair_variant=2, debug=33554432)      # one launch for kick + thermostat, but no k_boundary_radi (which also opens the next plain step)
+    # (debug bit 131072: without the pair kernel's fused epilogue, which since round 3 closes and opens such steps itself where no clean-up launch follows -
+    #  test_radiative_thermostat_fused_into_the_pair_kernel; this test is about the boundary kernel that serves everywhere else)
+    a = engine(case, pair_variant=2, debug=131072)
+    b = engine(case, pair_variant=2, debug=4194304 | 131072)
+    c = engine(case, pair_variant=2, debug=33554432 | 131072)      # one launch for kick + thermostat, but no k_boundary_radi (which also opens the next plain step)
     o = oracle.Oracle(case)
     o.forces(1)
     for n in (3, 20, 1, 16, 37):
@@ -1107,3 +1109,45 @@ def test_window_run_again_without_the_cleanup_launch_is_exact(kind):
             assert abs(sta[k] - stb[k]) <= 1e-11 * abs(stb[k]), (k, sta[k], stb[k])
             assert abs(sta[k] - stc[k]) <= 1e-9 * abs(stc[k]), (k, sta[k], stc[k])
     assert sta["step"] == stb["step"] == stc["step"] == 155
+
+
+@pytest.mark.parametrize("kind", ["gas", "liquid", "two_species", "equil"])
+def test_radiative_thermostat_fused_into_the_pair_kernel(kind):
+    """Runs with the radiative thermostat whose pair kernel reads no radii (case study 1): on plain steps of a lazy run without a clean-up launch the epilogue of
+    k_pair_list closes the step as k_integrate2_post does (second half-kick, then the thermostat on the fully kicked velocity, random draws keyed by the number of
+    the step being closed) and opens the next one - one launch per step instead of two.  Same operations in the same order: positions, velocities, forces and
+    the thermostat's per-atom energy and radius must be BIT-IDENTICAL to a run with the fusion switched off (debug bit 131072), whatever the pattern of calls;
+    energies equal to summation order, and both equal to the oracle.  'equil': an equilibration schedule - the steps it acts on (and their neighbours) take
+    the unfused path."""
+    if kind == "gas":        # the dilute gas of case study 1 in small: cells of 20 atoms' worth of empty space
+        rng = np.random.Generator(np.random.PCG64(77))
+        N, L = 3000, 480.0
+        g = 15
+        site = rng.permutation(g ** 3)[:N]
+        pos = np.stack([site // (g * g), (site // g) % g, site % g], axis=1) * (L / g) + L / (2 * g) + rng.uniform(-10.0, 10.0, size=(N, 3))
+        pos = np.round(np.mod(pos, L), 6)
+        case = inputs.lj_case((2, 2, 2), a=5.4, seed=1, rc=4.0, cell_list=80.0, T=298.0, tstat="radi", radii=[(2.73, 4.731, 0.2)])
+        case.update(box=[L, L, L], types=np.zeros(N, dtype=np.int32), x=pos[:, 0].copy(), y=pos[:, 1].copy(), z=pos[:, 2].copy(), vx=np.zeros(N), vy=np.zeros(N), vz=np.zeros(N))
+    elif kind == "two_species":
+        case = inputs.lj_case((8, 8, 8), a=5.6, seed=43, rc=7.5, cell_list=7.9, T=250.0, tstat="radi", vel_T=200.0, charges=(0.3, -0.3), elec="fenn", r_real=7.5, alpha=0.3,
+                              radii=[(2.73, 4.731, 0.2), (2.73, 4.731, 0.2)])
+    else:
+        case = inputs.lj_case((8, 8, 8), a=5.6, seed=44, rc=7.5, cell_list=7.9, T=250.0, tstat="radi", vel_T=200.0, radii=[(2.73, 4.731, 0.2)],
+                              nEq=60 if kind == "equil" else 0, freqEq=7)
+    a = engine(case, pair_variant=2)
+    b = engine(case, pair_variant=2, debug=131072)
+    o = oracle.Oracle(case)
+    o.forces(1)
+    for n in (10, 1, 37, 2, 33, 64, 5):
+        a.step(n); b.step(n); o.step(n)
+        sa, sb = a.state(), b.state()
+        for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz", "U", "radius"):
+            assert np.array_equal(sa[k], sb[k]), (n, k, rel_err(sa[k], sb[k]))
+    sta, stb, so, sto = a.stats(), b.stats(), o.state(), o.stats()
+    assert sta["pair_lists"] == 1 and sta["sort_interval"] > 1
+    assert sta["negCross"] + sta["posCross"] == stb["negCross"] + stb["posCross"]
+    for k in ("engVdW", "engCoul", "engKin", "engTemp", "engTot"):
+        assert abs(sta[k] - stb[k]) <= 1e-12 * max(abs(stb[k]), 1e-3), (k, sta[k], stb[k])
+    for k in ("x", "y", "z", "vx", "vy", "vz", "U"):
+        assert rel_err(sa[k], so[k]) < 1e-8, (k, rel_err(sa[k], so[k]))
+    assert abs(sta["engTemp"] - sto["engTemp"]) <= 1e-9 * max(abs(sto["engTemp"]), 1e-3)
