@@ -1181,7 +1181,9 @@ void Engine::launch_step_kernels()
         const bool lists = listsOn_ && lazyOn_ && lazyK_ > 1 && pair_variant() == 2;
         fuseNext_ = fuseNextOk_ && lists && nextPlain;
         // thermostat runs: only where no clean-up launch follows (it has no thermostat epilogue), on steps without equilibration scaling, never with energies on every step
-        if (fuseNextTstat_) fuseNext_ = fuseNext_ && optimistic_ && !equil && !(debug_ & DBG_ENERGIES_EVERY_STEP);
+        // (and one wave per cell: in the multi-wave kernels of dense systems the thermostat's registers cost the loop more than the launch saves -
+        //  measured with a second radius array for case study 2's surk kernel: S40 0.076 -> 0.093 ms/step, case study 2 unchanged; not kept)
+        if (fuseNextTstat_) fuseNext_ = fuseNext_ && optimistic_ && !equil && listWaves_ == 1 && !(debug_ & DBG_ENERGIES_EVERY_STEP);
     }
     pairClosedStep_ = false;
     sort_and_forces(stepMode);
