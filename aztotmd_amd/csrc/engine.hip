@@ -1762,6 +1762,8 @@ void Engine::get_stats(aztot_stats& out)
     sync();
     DevStats s;
     HIP_CHECK(hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost));
+    // (the host decides from its own count of the steps which of them the equilibration schedule acts on: the two counts must never part)
+    if (s.step != hostStep_) throw std::runtime_error("the host's step count (" + std::to_string(hostStep_) + ") and the device's (" + std::to_string(s.step) + ") differ");
     double v[24];
     v[0] = s.engKin; v[1] = s.engVdW; v[2] = s.engCoul; v[3] = s.engElecField; v[4] = s.engTemp;
     for (int k = 0; k < 6; k++) { v[5 + k] = s.mom[k]; v[11 + k] = (double)s.cross[k]; }
