@@ -1734,6 +1734,9 @@ bool Engine::adapt_sort_interval()
             static const int allowed[] = {64, 56, 48, 40, 36, 32, 28, 24, 20, 16, 14, 12, 10, 8, 6, 5, 4, 3, 2, 1};
             fromSpeed = 1;
             for (int a : allowed) if (a <= lazyCap_ && (double)a <= raw) { fromSpeed = a; break; }
+            // (the table keeps the number of different cycle lengths - captured graphs - small; where cycles are launched kernel by kernel any whole number will do:
+            //  a thermalised 1 M-atom liquid sits between 14 and 16 and gets 15)
+            if (!can_graph() && raw >= 1.0) fromSpeed = std::max(fromSpeed, std::min(lazyCap_, (int)raw));
         }
         // after a violation: half the interval, or what the speeds seen now allow if that is less (a melt that heats up outruns halving)
         if (violated) K = std::max(1, fromSpeed > 0 ? std::min(K / 2, fromSpeed) : K / 2);
