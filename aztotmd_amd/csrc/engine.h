@@ -148,7 +148,7 @@ private:
     long long lazyViolations_ = 0;
     int lazyWindow_ = 8;               // steps between two looks at the speeds: 8, 16, ... 256
     int sinceLook_ = 0;                // steps since the last look (runs on across calls)
-    double lazyMargin_ = 1.5;          // one GPU: K steps of the longest step seen may use slack / lazyMargin_; widened by every violation (a system that heats up)
+    double lazyMargin_ = 1.3;          // one GPU: K steps of the longest step seen may use slack / lazyMargin_; widened by every violation (a system that heats up)
     bool lazyMeasured_ = false;     // the interval has been sized from a measurement at least once
     int sinceSort_ = 1 << 30;       // plain steps since the last sort
     long long rebuilds_ = 0;        // steps that rebuilt the cell list so far
