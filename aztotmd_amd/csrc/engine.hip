@@ -1476,7 +1476,7 @@ void Engine::run_steps(int nsteps)
     // Lazy re-sort (one GPU): the reference rebuilds its cell list every step (main.cu:300-326); here a step re-sorts only every lazyK_-th time.  That is
     // exact as long as no atom is farther than (stencil reach - rc) / 2 from where it was when the cells were built: every pair inside rc is then still
     // found in the stencil of the cell the atoms were sorted into.  Plain steps leave slots, cells and buffers alone, keep coordinates unwrapped, count
-    // wall crossings when they happen, and check every atom's displacement; should one ever leave the slack (the interval is sized with a factor 1.5 to
+    // wall crossings when they happen, and check every atom's displacement; should one ever leave the slack (the interval is sized with a factor 1.3 to
     // spare from the largest step seen), the pair kernels reach one cell further until the next sort - slower, still exact.  The first step of
     // every call sorts (the deferred half-kick is re-armed by the scan).
     // With pair lists a sort interval runs on from the previous call when nothing has touched the state since (the lists are those of the arrays as they
@@ -1576,7 +1576,7 @@ void Engine::prepare_next_call()
     if (can_graph()) (void)graph_for_state(graph_cycle());
 }
 
-// the largest step any atom made since the last look sizes the next calls' sort interval: K steps of that length use at most two thirds of the slack
+// the largest step any atom made since the last look sizes the next calls' sort interval: K steps of that length use at most slack / 1.3 (Engine::lazyMargin_)
 // (one GPU; a violation is handled exactly by the clean-up launch at the staging kernel's speed, so the margin is a performance choice: with half the
 // slack C4 ran at K = 16, with two thirds at K = 24-28, no violation in 2 000 steps; every violation widens the margin for good - a system that heats up,
 // like the Born-Mayer-Huggins melt B3, would otherwise run into one after the other) - half on slab ranks, whose repair (a window of steps run again) is dearer.
@@ -1718,7 +1718,7 @@ bool Engine::adapt_sort_interval()
             const int32_t z = 0;
             HIP_CHECK(hipMemcpy(&dCounts_->lazyViolatedEver, &z, sizeof(z), hipMemcpyHostToDevice));
             lazyViolations_++;
-            lazyMargin_ = std::min(4.0, lazyMargin_ * (4.0 / 3.0));      // the speeds are growing: more room from now on (1.5 -> 2 -> 2.7 -> 3.6 -> 4)
+            lazyMargin_ = std::min(4.0, lazyMargin_ * (4.0 / 3.0));      // the speeds are growing: more room from now on (1.3 -> 1.7 -> 2.3 -> 3.1 -> 4)
         }
         int fromSpeed = -1;
         if (c.maxStep2 != 0)
