@@ -2,7 +2,10 @@
 """bench.py - ns/day of the azTotMD per-step hot path on MI355X (see DESIGN.md "Measurement").
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+N > 1 either way: under a launcher that sets RANK / WORLD_SIZE (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+--gpus N ...) this process IS one rank; started plainly (no WORLD_SIZE in the environment) it becomes the launcher itself - before it loads
+libaztot or makes any HIP call it starts N fresh rank processes of this script, relays rank 0's JSON line and exits with the worst exit
+code among them (launch_ranks).
 
 Workload (BASELINE.json config "1 000 000 Ar LJ", SURVEY 8d "C4"): 1 000 188 argon atoms, FCC 63^3 cells of
 5.735 A with +-0.15 A jitter (seed 20240502), LJ eps 0.01006 eV sigma 3.3952 A, cut-off 8.5 A, dt 1 fs, NVE,
@@ -55,7 +58,89 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels (enables hipGraph replay)")
     ap.add_argument("--no-graph", action="store_true", help="A/B aid: launch every kernel eagerly instead of replaying captured cycles")
     ap.add_argument("--split", type=int, default=0, help="A/B aid: waves per cell in the staging pair kernel (0: the engine decides)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher check: every rank reports its environment through the control plane and exits without touching a GPU")
     return ap.parse_args()
+
+
+EXIT_RCCL_FAILED = 3        # one GPU per rank and RCCL did not come up
+EXIT_REHEARSAL = 4          # fewer GPUs than ranks: the line printed is a rehearsal (host-staged halo), never a result
+GPU_LIBRARIES = ("libaztot", "libamdhip64", "libhsa-runtime", "librccl")
+
+
+def mapped_gpu_libraries(pid="self"):
+    """GPU runtime libraries mapped into a process (the launcher must have none: it never re-executes or forks a process that touched the GPU)"""
+    try:
+        maps = open("/proc/%s/maps" % pid).read()
+    except OSError:
+        return None
+    return sorted({g for g in GPU_LIBRARIES if g in maps})
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (fresh interpreters, one per GPU), hand them RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* and a per-run control-plane token, relay rank 0's stdout (the ONE JSON line), send every other rank's stdout to stderr, and
+    return the worst exit code.  Nothing here imports the package, loads libaztot or calls HIP."""
+    import secrets
+    import signal
+    import socket
+    import threading
+    assert not mapped_gpu_libraries(), "the launcher must not have touched the GPU"
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:           # a free port for the control plane (the ranks use nothing else on it)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AZTOT_CTL_PORT_OFFSET="0",
+               AZTOT_CTL_TOKEN=secrets.token_hex(16), AZTOT_BENCH_LAUNCHER_PID=str(os.getpid()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e, stdout=subprocess.PIPE, stderr=None, start_new_session=True))
+
+    def relay(proc, to):
+        for line in proc.stdout:
+            to.write(line)
+            to.flush()
+
+    threads = [threading.Thread(target=relay, args=(p, sys.stdout.buffer if r == 0 else sys.stderr.buffer), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    worst, first_failure = 0, None
+    live = set(range(n))
+    try:
+        while live:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0:
+                    worst = max(worst, rc if rc > 0 else 128 - rc)
+                    if first_failure is None:
+                        first_failure = time.time()
+                        sys.stderr.write("bench.py launcher: rank %d exited with code %d\n" % (r, rc))
+            if first_failure is not None and live and time.time() - first_failure > 30.0:
+                # a rank died: the others would wait for it in a collective until the control plane's timeout - end exactly the process groups started here
+                for r in sorted(live):
+                    sys.stderr.write("bench.py launcher: ending rank %d (pid %d) after another rank failed\n" % (r, procs[r].pid))
+                    try:
+                        os.killpg(procs[r].pid, signal.SIGTERM)
+                    except OSError:
+                        pass
+                first_failure = time.time() + 1e9
+                worst = max(worst, 1)
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        worst = max(worst, 130)
+    for t in threads:
+        t.join(timeout=5.0)
+    return worst
 
 
 def cpu_baseline(case, steps):
@@ -123,6 +208,9 @@ WORKLOADS = {"C4": "1 000 188 Ar, LJ rc 8.5 A, FCC 63^3 a=5.735 jitter 0.15, dt 
 
 def main():
     a = parse()
+    if a.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1 and "AZTOT_BENCH_LAUNCHER_PID" not in os.environ:
+        # started plainly with --gpus N: this process only launches the ranks (a plain `python bench.py --gpus 8` ran ONE rank)
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     # the contract is ONE JSON line on stdout: keep library chatter (RCCL, HIP runtime) away from it
     sys.stdout.flush()
     real_stdout = os.dup(1)
@@ -138,6 +226,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world > 1:
         a.gpus = world
+    if a.dry_run:
+        # what a rank was handed, gathered over the control plane; no GPU library is loaded in any process of a dry run
+        lp = os.environ.get("AZTOT_BENCH_LAUNCHER_PID")
+        mine = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid(), "ppid": os.getppid(), "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
+                "token_set": bool(os.environ.get("AZTOT_CTL_TOKEN")), "gpu_libraries": mapped_gpu_libraries()}
+        ranks = cp.all_gather(mine)
+        if rank == 0:
+            os.dup2(real_stdout, 1)
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": ranks, "launcher_pid": int(lp) if lp else None,
+                              "launcher_gpu_libraries": mapped_gpu_libraries(lp) if lp else None}), flush=True)
+        cp.barrier()
+        cp.close()
+        return
     ndev = api.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -189,7 +290,7 @@ def main():
             sys.stderr.write("bench.py rank %d: RCCL initialisation failed with one GPU per rank: %s\n" % (rank, err if not ok else "on another rank"))
             cp.barrier()
             cp.close()
-            raise SystemExit(3)
+            raise SystemExit(EXIT_RCCL_FAILED)
         # rehearsal on a box with fewer GPUs than ranks (RCCL cannot put two ranks on one device): host-staged transport relayed by the
         # control plane, clearly labelled, never a result
         slab = {"rank": rank, "nranks": world, "sendrecv": lambda sp, data, rp, rcap: cp.sendrecv(sp, bytes(data), rp),
@@ -379,6 +480,9 @@ def main():
     if world > 1:
         cp.barrier()
     cp.close()
+    if oversubscribed:
+        # the line above says "REHEARSAL ... not a result"; the exit code says so too (a scaling record must not be built from it)
+        raise SystemExit(EXIT_REHEARSAL)
 
 
 if __name__ == "__main__":
