@@ -105,11 +105,22 @@ def build_library(force=False):
     """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
     so = library_path()
-    newest = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir))
+    newest = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir) if f.endswith((".h", ".hip", ".cpp")) or f == "Makefile")
     hdr = os.path.join(os.path.dirname(_HERE), "include", "aztot.h")
     newest = max(newest, os.path.getmtime(hdr))
-    if force or not os.path.exists(so) or os.path.getmtime(so) < newest:
-        subprocess.check_call(["make", "-C", src_dir, "all"], stdout=subprocess.DEVNULL)
+    def stale():
+        return force or not os.path.exists(so) or os.path.getmtime(so) < newest
+
+    if stale():
+        # N ranks started against a stale library would run N makes over the same object files: one builds, the others wait and find it done
+        import fcntl
+        with open(os.path.join(src_dir, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    subprocess.check_call(["make", "-C", src_dir, "all"], stdout=subprocess.DEVNULL)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return so
 
 

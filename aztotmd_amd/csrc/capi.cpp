@@ -44,7 +44,11 @@ int guarded(F&& f)
 extern "C" {
 
 const char* aztot_last_error(void) { return g_err.c_str(); }
-const char* aztot_version(void) { return "aztotmd_amd 0.1 (gfx950, fp64)"; }
+#ifndef AZTOT_SRC_HASH
+#define AZTOT_SRC_HASH "unknown"
+#endif
+// "... src <16 hex digits>": a digest of every source file the library was compiled from (csrc/Makefile)
+const char* aztot_version(void) { return "aztotmd_amd 0.4 (gfx950, fp64) src " AZTOT_SRC_HASH; }
 
 int aztot_init_md(const char* dir, aztot_model** out)
 {

@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="do not time individual kernels (enables hipGraph replay)")
     ap.add_argument("--no-graph", action="store_true", help="A/B aid: launch every kernel eagerly instead of replaying captured cycles")
     ap.add_argument("--split", type=int, default=0, help="A/B aid: waves per cell in the staging pair kernel (0: the engine decides)")
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady_state / call_overhead blocks")
+    ap.add_argument("--steady-steps", type=int, default=300)
     ap.add_argument("--dry-run", action="store_true", help="launcher check: every rank reports its environment through the control plane and exits without touching a GPU")
     return ap.parse_args()
 
@@ -345,7 +347,7 @@ def main():
         out = {
             "metric": "ns_per_day", "value": None, "unit": "ns/day", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "library": api.lib().aztot_version().decode(),
             "config": {"workload": WORKLOADS.get(a.workload, a.workload),
                        "n_atoms": n_atoms, "n_cells": st["n_cells"], "decomposition": "single GPU" if world == 1 else "%d slabs along x" % world, "transport": transport, "rccl_ranks": rccl_ranks, "ranks_share_gpus": oversubscribed,
                        "pair_variant": a.pair_variant, "sort_interval": st.get("sort_interval"), "sort_violations": st.get("sort_violations"), "skin_A": st.get("skin"),
@@ -386,15 +388,22 @@ def main():
                 t_pair = kern[pair_name]["avg_us"] * 1e-6
                 n_rank = n_atoms / (a.emulate_ranks if a.emulate_ranks > 1 else world)       # atoms one rank's pair kernel serves
                 alg = PAIR_BYTES_PER_ATOM * n_rank + PAIR_BYTES_PER_CELL * st["n_cells"] / world
+                # PMC counters cannot be collected inside this run (rocprofv3 wraps the process); they come from profiles/pmc_traffic.json, whose entries name
+                # the library build they were measured on (tools/make_profiles.py records aztot_version's source digest and the kernel symbol).  An entry
+                # from another build is NOT replayed: traffic / fp64 figures are null then, and `counters_stale` says what was found
                 traffic = flop = None
-                rec = {}
+                rec, stale = {}, None
                 tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
                 if os.path.exists(tp) and a.emulate_ranks <= 1:        # (the counters were collected on the whole system: they say nothing about one rank's share)
                     try:
                         rec = json.load(open(tp)).get("%s:%s:%d" % (a.workload, pair_name, world)) or {}
+                    except Exception:
+                        rec = {}
+                    if rec and rec.get("library") == out["library"]:
                         traffic = rec.get("hbm_bytes_per_launch")
                         flop = rec.get("fp64_flop_per_launch")
-                    except Exception:
+                    elif rec:
+                        stale = {"measured_on": rec.get("library", "a build that left no fingerprint (%s)" % rec.get("round")), "running": out["library"]}
                         rec = {}
                 # SURVEY 8d asks for three numbers side by side: (1) compulsory-byte fraction of the HBM roofline, (2) the measured HBM
                 # rate (PMC bytes / launch time; a traffic measure), (3) FP64 FLOP / time / FP64-vector peak (what actually bounds it)
@@ -406,7 +415,7 @@ def main():
                                    "fp64_tflops": (flop / t_pair / 1e12) if flop else None,
                                    "fp64_frac": (flop / t_pair / FP64_VECTOR_PEAK) if flop else None,
                                    "fp64_peak_tflops": FP64_VECTOR_PEAK / 1e12,
-                                   "counters_from": rec.get("round"),
+                                   "counters_from": rec.get("round"), "counters_kernel": rec.get("kernel"), "counters_stale": stale,
                                    "note": "frac counts the COMPULSORY bytes (52 B/atom + 8 B/cell); traffic is what the kernel really moves - pair_list streams its "
                                            "candidate and pair lists (recorded when the cells were rebuilt) once per step, which is what replaces "
                                            "staging, filtering and mask handling; fp64_flop_per_launch = (2 FMA + ADD + MUL + TRANS) x 64 from the "
@@ -420,6 +429,42 @@ def main():
                     t_k = kern[k]["avg_us"] * 1e-6
                     stream[k] = {"bytes_per_atom": bb, "avg_us": kern[k]["avg_us"], "gbps": bb * n_local / t_k / 1e9, "hbm_frac": bb * n_local / t_k / HBM_PEAK}
             out["streaming"] = stream
+        if world == 1 and a.emulate_ranks <= 1 and not a.no_steady:
+            # (a) steady state: the timed window above is whatever --steps / --warmup the caller chose (the driver: 20 after 5 - inside the clock ramp of a
+            # fresh process); this is the same engine a few hundred steps later, one long call.  (b) call overhead: the reference's loop is per step
+            # (main.cu:281-410), so a caller that couples something to every step calls aztot_step(1) - each call ends with the deferred half-kick,
+            # the statistics reduction, a stream synchronisation and the look at the sort interval
+            try:
+                ns = a.steady_steps
+                eng.step(ns)
+                api.device_synchronize(dev)
+                r0 = eng.stats()["rebuilds"]
+                t0 = time.perf_counter()
+                eng.step(ns)
+                api.device_synchronize(dev)
+                w = time.perf_counter() - t0
+                s1 = eng.stats()
+                out["steady_state"] = {"steps": ns, "warmup": ns, "ms_per_step": w / ns * 1e3, "ns_per_day": ns * dt_ps * 1e-3 / w * 86400.0,
+                                       "rebuilds_in_timed_region": s1["rebuilds"] - r0, "sort_interval": s1["sort_interval"]}
+                n1 = 200
+                t0 = time.perf_counter()
+                for _ in range(n1):
+                    eng.step(1)
+                api.device_synchronize(dev)
+                w1 = time.perf_counter() - t0
+                stat = max(int(model.query("stat")[0]), 1)
+                ncall = max(2, 400 // stat)
+                t0 = time.perf_counter()
+                for _ in range(ncall):
+                    eng.step(stat)
+                    eng.stats()
+                api.device_synchronize(dev)
+                w2 = time.perf_counter() - t0
+                out["call_overhead"] = {"step1_calls": n1, "step1_ms_per_step": w1 / n1 * 1e3, "step1_over_long_call": (w1 / n1) / (w / ns),
+                                        "stat_interval": stat, "step_stat_calls": ncall, "step_stat_ms_per_step": w2 / (ncall * stat) * 1e3,
+                                        "step_stat_over_long_call": (w2 / (ncall * stat)) / (w / ns)}
+            except Exception as ex:   # noqa: BLE001
+                out["steady_state"] = "failed: %r" % (ex,)
         if world == 1 and not a.no_cpu_baseline and a.emulate_ranks <= 1:
             # the same timed region with pair energies booked on every step (options.energies_every_step): what a caller who asks for statistics after every
             # single step would see

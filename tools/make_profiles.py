@@ -56,6 +56,15 @@ if os.path.isdir(fp64_dir):
             shutil.copy(src, os.path.join(P, "%s_rocprofv3_pmc_%s" % (tag, f.replace("_summary", "_counters"))))
 tp = os.path.join(P, "pmc_traffic.json")
 rec = json.load(open(tp)) if os.path.exists(tp) else {}
+# which build the counters were collected on: the bench line printed under rocprofv3 carries aztot_version (with the digest of the library's sources);
+# bench.py replays an entry only on that very build
+libs = set()
+for d in (fetch_dir, write_dir, fp64_dir):
+    try:
+        libs.add(json.loads(open(os.path.join(d, "bench_line.json")).read().strip().splitlines()[-1])["library"])
+    except Exception:
+        pass
+library = libs.pop() if len(libs) == 1 else None
 seen = {}        # several instantiations share a bench name (k_pair_list<.., ENG = true / false>): the one launched most often carries the run
 for r in rows:
     k = r["kernel"]
@@ -71,7 +80,7 @@ for r in rows:
         name = "pair_atom" if k == "k_pair_atom" else None
     if name and r["dispatches"] > seen.get(name, 0):
         seen[name] = r["dispatches"]
-        rec["%s:%s:%d" % (workload, name, ngpu)] = {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"], "fp64_flop_per_launch": flop.get(r["kernel"]), "round": tag, "kernel": r["kernel"],
+        rec["%s:%s:%d" % (workload, name, ngpu)] = {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"], "fp64_flop_per_launch": flop.get(r["kernel"]), "round": tag, "kernel": r["kernel"], "library": library,
                                                     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH doubled per MI355X_MICROARCH.md"}
 json.dump(rec, open(tp, "w"), indent=1)
 print(open(os.path.join(P, "%s_rocprofv3_pmc_hbm_traffic.csv" % tag)).read())
