@@ -91,7 +91,7 @@ SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
 
 EXPORTS = ("aztot_device_count", "aztot_device_synchronize", "aztot_init_md", "aztot_model_create", "aztot_model_set_bonded", "aztot_model_query", "aztot_model_species_name", "aztot_free_md", "aztot_default_options",
-           "aztot_init_device", "aztot_free_device", "aztot_step", "aztot_forces", "aztot_get_stats", "aztot_species_crossings", "aztot_md_to_host",
+           "aztot_init_device", "aztot_free_device", "aztot_step", "aztot_sync", "aztot_forces", "aztot_get_stats", "aztot_species_crossings", "aztot_md_to_host",
            "aztot_set_state", "aztot_get_clock", "aztot_set_clock", "aztot_cell_table", "aztot_kernel_times", "aztot_reset_kernel_times", "aztot_set_profile", "aztot_comm_id_bytes", "aztot_comm_make_id", "aztot_comm_selftest", "aztot_comm_ranks",
            "aztot_init_device_slab", "aztot_last_error", "aztot_version")
 
@@ -149,6 +149,7 @@ def lib():
         L.aztot_free_device.argtypes = [C.c_void_p]
         L.aztot_free_device.restype = None
         L.aztot_step.argtypes = [C.c_void_p, C.c_int]
+        L.aztot_sync.argtypes = [C.c_void_p]
         L.aztot_forces.argtypes = [C.c_void_p]
         L.aztot_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
         L.aztot_species_crossings.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
@@ -356,6 +357,10 @@ class Engine:
 
     def step(self, n=1):
         _check(lib().aztot_step(self.h, int(n)))
+
+    def sync(self):
+        """everything earlier calls queued or deferred has happened when this returns (aztot_sync): the end of a timed region"""
+        _check(lib().aztot_sync(self.h))
 
     def forces(self):
         _check(lib().aztot_forces(self.h))

@@ -271,6 +271,12 @@ int aztot_step(aztot_md* md, int nsteps)
     return guarded([&] { md->eng->step(nsteps); });
 }
 
+int aztot_sync(aztot_md* md)
+{
+    if (!md) return fail(AZTOT_ERR_ARG, "null handle");
+    return guarded([&] { md->eng->sync_all(); });
+}
+
 int aztot_forces(aztot_md* md)
 {
     if (!md) return fail(AZTOT_ERR_ARG, "null handle");

@@ -54,7 +54,8 @@ enum DebugBit : unsigned
     DBG_PLAIN_ONE_ATOM = 16777216,       // plain steps integrate one atom per thread
     DBG_NO_BOUNDARY_RADI = 33554432,     // thermostat runs close a step and open the next in two launches
     DBG_ONE_WAVE_PER_CELL = 67108864,    // one wave per cell in the staging kernel whatever the system
-    DBG_ENERGIES_EVERY_STEP = 134217728  // = options.energies_every_step
+    DBG_ENERGIES_EVERY_STEP = 134217728, // = options.energies_every_step
+    DBG_SETTLE_EVERY_CALL = 268435456    // every aztot_step call ends with the look / statistics / synchronisation (one GPU defers them to the next look or read)
 };
 
 class Engine
@@ -75,11 +76,19 @@ public:
     int cell_table(int32_t dims[3], int32_t* cellStart, int capCells, int32_t* atomId, int capAtoms);
     int kernel_times(std::vector<KernelTimer>& out);
     void reset_kernel_times();
-    void set_profile(bool on) { sync(); profile_ = on; }
+    void set_profile(bool on) { settle(); sync(); profile_ = on; }
     int n_atoms_global() const { return model_.nAt; }
     int comm_ranks() const { return xch_ ? xch_->comm_ranks() : 0; }
+    void sync_all();                        // everything queued or deferred by earlier calls has happened when this returns (aztot_sync)
 
 private:
+    void step_body(int nsteps);
+    bool settle_now() const;
+    void settle();
+    void mark_failed(const char* what) noexcept;
+    void regrow_lists(int candCap, int iterCap);
+    bool unsettled_ = false;                // the last aztot_step call returned with its end (deferred kick, statistics, look) still to come: Engine::settle
+    std::string failed_;                    // first error of a step / settle: the handle no longer steps, reads still work
     void construct();
     void release();
     void destroy_graphs();
@@ -264,7 +273,7 @@ private:
     // nearly always has nothing to do): the same snapshots let the plain steps run WITHOUT it.  A look that finds a violation or a cell that kept no list
     // goes back and runs the window again with the launch in place (exact as before), and the run stays on the safe side for a few looks.
     bool optimistic_ = false;
-    int safeLooks_ = 2;             // looks still to be spent with the clean-up launch in place (an engine's first two; 8, 16, 32 ... after a window had to be run again)
+    int safeLooks_ = 1;             // looks still to be spent with the clean-up launch in place (an engine's first; 8, 16, 32 ... after a window had to be run again)
     int rollbacks_ = 0;
     bool unlistedAtLook_ = false;   // the last look found cells recorded without a list
     void choose_optimism();

@@ -34,6 +34,7 @@ constexpr int kFuseKickMaxAtoms = 262144;
 constexpr int kLazyCapMax = 128;         // longest sort interval (steps)
 constexpr int kListCandMax = 1920;       // the LDS tile of k_pair_list holds candCap + 1 records of 32 B next to a 1 KiB table: below 64 KiB
 constexpr int kListIterMax = 248;
+constexpr long long kSnapshotKeepSteps = 32;     // a verified snapshot younger than this is kept at the end of a call (Engine::settle)
 }  // namespace
 
 template <typename F>
@@ -80,8 +81,8 @@ void Engine::sync()
     if (profile_) drain_events();
 }
 
-int Engine::kernel_times(std::vector<KernelTimer>& out) { sync(); out = timers_; return (int)out.size(); }
-void Engine::reset_kernel_times() { sync(); for (auto& t : timers_) { t.ms = 0; t.calls = 0; } }
+int Engine::kernel_times(std::vector<KernelTimer>& out) { settle(); sync(); out = timers_; return (int)out.size(); }
+void Engine::reset_kernel_times() { settle(); sync(); for (auto& t : timers_) { t.ms = 0; t.calls = 0; } }
 
 // ---------------------------------------------------------------------------------------------------
 // cell grid: split_cells (cuCellList.cu:9-34, div_type 1: edge >= requested size).  No pair tables are
@@ -637,6 +638,20 @@ void Engine::allocate_lists(int candCap, int iterCap)
                      (double)(nc * ((size_t)candCap * 4 + (size_t)iterCap * 128)) / 1e6, pair_list_lds_bytes(P_, pair_lists()), build_lists_lds_bytes(pair_lists()));
 }
 
+// Larger lists in the middle of a run (adapt_sort_interval).  allocate_lists frees the old ones first; if the new ones do not fit the run goes on
+// without lists - the steps between two rebuilds stage every cell, as after a failed allocation at construction - instead of failing the call half-way
+// through a look (on slab ranks the other ranks would be left waiting in the look's all-reduce: ADVICE round 3).
+void Engine::regrow_lists(int candCap, int iterCap)
+{
+    try { allocate_lists(candCap, iterCap); }
+    catch (const std::exception& e)
+    {
+        (void)hipGetLastError();
+        free_lists();
+        if (std::getenv("AZTOT_VERBOSE")) std::fprintf(stderr, "aztot: rank %d: no room for larger pair lists (%s): the run goes on without lists\n", rank_, e.what());
+    }
+}
+
 void Engine::free_lists()
 {
     if (stream_) (void)hipStreamSynchronize(stream_);
@@ -1144,6 +1159,8 @@ void Engine::collect_and_finalize(unsigned slotMask)
 
 void Engine::forces(bool withBonded)
 {
+    if (!failed_.empty()) throw std::runtime_error("this handle failed in an earlier call: " + failed_);
+    settle();
     snap_.valid = false;
     sinceSort_ = 1 << 30;           // a sort interval does not run on through a force call (it re-bins wrapped coordinates)
     sort_and_forces(0, withBonded);
@@ -1267,7 +1284,9 @@ void Engine::finish_steps()
 // kernel arguments, so a change drops the captured graphs)
 void Engine::choose_optimism()
 {
-    const bool want = nranks_ == 1 && lazyOn_ && listsOn_ && lazyMeasured_ && lazyK_ > 1 && pair_variant() == 2 && capacity_ <= 2 * kFuseKickMaxAtoms &&
+    // (any size since round 4: on 1 M atoms the launch cost 6.9 us of a 123 us step - the drain and refill of the chip around a kernel that finds nothing
+    //  to do -, a snapshot is 100 MB = 33 us per look, and looks are up to 256 steps apart)
+    const bool want = nranks_ == 1 && lazyOn_ && listsOn_ && lazyMeasured_ && lazyK_ > 1 && pair_variant() == 2 &&
                       safeLooks_ == 0 && !unlistedAtLook_ && unlistedState_ != 2 && !(debug_ & DBG_ALWAYS_CLEANUP);
     if (want != optimistic_)
     {
@@ -1342,17 +1361,107 @@ void Engine::replay_from_snapshot()
     stepsSinceSnap_ = n;
 }
 
+// An error inside a call leaves the host's picture of the device (cycles, lists, the deferred kick, its own step count) unreliable: the handle is dead
+// for stepping from then on and says why; reads (aztot_get_stats, aztot_md_to_host, aztot_get_clock) still work for a post-mortem and report what the
+// device holds (a secondary "step counts differ" error used to hide the first one).
+void Engine::mark_failed(const char* what) noexcept
+{
+    if (failed_.empty()) failed_ = what ? what : "unknown error";
+    unsettled_ = false;
+    snap_.valid = false;
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    (void)hipGetLastError();
+    DevStats s;
+    if (dStats_ && hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost) == hipSuccess) hostStep_ = s.step;
+    (void)hipGetLastError();
+}
+
 void Engine::step(int nsteps)
 {
     if (nsteps <= 0) return;
+    if (!failed_.empty()) throw std::runtime_error("this handle failed in an earlier call and cannot step on: " + failed_);
+    try { step_body(nsteps); }
+    catch (const std::exception& e) { mark_failed(e.what()); throw; }
+    catch (...) { mark_failed("unknown exception"); throw; }
+}
+
+// Does this call end with the look / statistics / read-backs right away?  Slab ranks (collectives every rank must take together), bonded terms and pair
+// kernel 3 (overflow flags to read back), per-kernel timing (events to drain): always.  One GPU otherwise: only when a look at the sort interval is due
+// (8, 16, ... 256 steps after the last one, or never made) - else the call returns with its kernels queued, and whoever reads state or statistics next
+// (or the next look) settles: a caller that steps one step at a time (the reference's loop is per step, main.cu:281-410) pays for the second half-kick
+// launch, the statistics reduction, the stream synchronisation and the snapshot once per look instead of once per step.
+bool Engine::settle_now() const
+{
+    if (nranks_ > 1 || hasBonded_ || profile_ || pair_variant() == 3 || (debug_ & DBG_SETTLE_EVERY_CALL)) return true;
+    if (!lazyOn_) return false;
+    return !lazyMeasured_ || sinceLook_ >= lazyWindow_;
+}
+
+// The end of a call, possibly deferred (settle_now): the deferred second half-kick and the statistics of the last step, the look at the sort interval
+// (a window of steps run again where it finds a skin violation that nothing had repaired on the spot), overflow checks on the state the caller will see,
+// what the next call needs.
+void Engine::settle()
+{
+    if (!unsettled_ || !failed_.empty()) return;
+    unsettled_ = false;
+    try
+    {
+        const int windowCap = nranks_ > 1 ? 64 : 256;
+        finish_steps();
+        check_launch("end-of-call kernels");
+        look_sync();
+        if (lazyOn_)
+        {
+            if (!adapt_sort_interval())
+            {
+                replay_from_snapshot();
+                kickOwed_ = lazyKick_;
+                finish_steps();
+                check_launch("step kernels (run again)");
+                look_sync();
+                if (!adapt_sort_interval()) throw std::runtime_error("lazy re-sort: a skin violation in a run that rebuilds its cells every step");
+            }
+            if (2 * sinceLook_ >= lazyWindow_) lazyWindow_ = std::min(windowCap, 2 * lazyWindow_);      // (this look stands in for the one that was due)
+            sinceLook_ = 0;
+            if (safeLooks_ > 0) safeLooks_--;
+        }
+        // (on the state the caller will see: an optimistic window that had to be run again is inexact until it has been - ADVICE round 3)
+        check_overflow();
+        prepare_next_call();
+        if (lazyOn_)
+        {   // (behind prepare_next_call: it may have recorded the engine's first lists and knows whether every cell got one)
+            choose_optimism();
+            // The snapshot a later look may have to go back to.  A verified one that is still young is kept (going back a few steps further costs a little
+            // more in the rare case, a 100 MB copy per call costs every caller that steps in short calls)
+            if (!rollback_on()) snap_.valid = false;
+            else if (!snap_.valid || stepsSinceSnap_ >= kSnapshotKeepSteps) take_snapshot();
+        }
+    }
+    catch (const std::exception& e) { mark_failed(e.what()); throw; }
+}
+
+void Engine::sync_all()
+{
+    settle();
+    sync();
+}
+
+void Engine::step_body(int nsteps)
+{
     // The sort interval is re-evaluated ("a look": a stream synchronisation and a few small read-backs, ~0.1 ms with the pipeline refill) at the end of every
     // call and, inside long calls, whenever lazyWindow_ steps have gone by since the last look - 8, 16, 32, ... then every 256 (a run that starts from rest speeds
     // up for a while: the looks are close together where that happens).  The count runs on across calls (sinceLook_), and a look is skipped when the call
     // ends within half a window anyway: a short call right behind a look - the driver's 20 steps after 5 of warm-up - pays for no look of its own.
     const int windowCap = nranks_ > 1 ? 64 : 256;     // (a slab rank repairs a skin violation by running the window again: it looks more often)
-    choose_optimism();
+    // (a call whose end was deferred - settle_now - and that nobody has looked at since: its second half-kick is still owed on the device, DevStats::pendingKick,
+    //  and this call's first integrate kernel pays it exactly as it does between two steps of one call; its statistics were never asked for)
+    kickOwed_ = false;
+    if (!unsettled_)
+    {
+        choose_optimism();
+        if (rollback_on() && !snap_.valid) take_snapshot();         // (the state as the caller left it: set_state / aztot_forces / the first call)
+    }
     bool roll = rollback_on();
-    if (roll && !snap_.valid) take_snapshot();         // (the state as the caller left it: set_state / aztot_forces / the first call)
     int left = nsteps;
     while (left > 0)
     {
@@ -1383,32 +1492,9 @@ void Engine::step(int nsteps)
         }
     }
     kickOwed_ = lazyKick_;          // set here, not in launch_step_kernels: a replayed graph does not pass through the host code
-    finish_steps();
     check_launch("step kernels");
-    look_sync();
-    check_overflow();
-    if (lazyOn_)
-    {
-        if (!adapt_sort_interval())
-        {
-            replay_from_snapshot();
-            kickOwed_ = lazyKick_;
-            finish_steps();
-            check_launch("step kernels (run again)");
-            look_sync();
-            check_overflow();
-            if (!adapt_sort_interval()) throw std::runtime_error("lazy re-sort: a skin violation in a run that rebuilds its cells every step");
-        }
-        if (2 * sinceLook_ >= lazyWindow_) lazyWindow_ = std::min(windowCap, 2 * lazyWindow_);      // (this look stands in for the one that was due)
-        sinceLook_ = 0;
-        if (safeLooks_ > 0) safeLooks_--;
-    }
-    prepare_next_call();
-    if (lazyOn_)
-    {   // (behind prepare_next_call: it may have recorded the engine's first lists and knows whether every cell got one)
-        choose_optimism();
-        if (rollback_on()) take_snapshot(); else snap_.valid = false;
-    }
+    unsettled_ = true;
+    if (settle_now()) settle();
 }
 
 // steps per graph: one sort interval; with the cells rebuilt every step the sort ping-pongs the buffers, so it takes two steps to come back
@@ -1640,7 +1726,7 @@ bool Engine::adapt_sort_interval()
                     const int candNew = std::max(candCap_, kListMinCand * wWant);
                     listWaves_ = wWant;
                     destroy_graphs(); graphCycle_ = 0;
-                    allocate_lists(candNew, itersNew);
+                    regrow_lists(candNew, itersNew);
                     rebuildNeeded = true;
                     nl[1] = 0;                                  // (what was recorded describes lists that no longer exist: nothing more to decide now)
                 }
@@ -1654,7 +1740,7 @@ bool Engine::adapt_sort_interval()
                 const int cand = nl[5] > 0 ? std::min(kListCandMax, (candCap_ * 3 / 2 + 63) & ~63) : candCap_;
                 const int iters = nl[6] > 0 ? std::min(kListIterMax, (iterCap_ * 2 + 7) & ~7) : iterCap_;
                 destroy_graphs(); graphCycle_ = 0;
-                if (listGrowths_ < 3 && (cand > candCap_ || iters > iterCap_)) { listGrowths_++; allocate_lists(cand, iters); rebuildNeeded = true; }
+                if (listGrowths_ < 3 && (cand > candCap_ || iters > iterCap_)) { listGrowths_++; regrow_lists(cand, iters); rebuildNeeded = true; }
             }
             else if (candLds != candLds_ || iterLds != iterLds_)
             {
@@ -1765,11 +1851,12 @@ void Engine::check_overflow()
 
 void Engine::get_stats(aztot_stats& out)
 {
+    settle();
     sync();
     DevStats s;
     HIP_CHECK(hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost));
     // (the host decides from its own count of the steps which of them the equilibration schedule acts on: the two counts must never part)
-    if (s.step != hostStep_) throw std::runtime_error("the host's step count (" + std::to_string(hostStep_) + ") and the device's (" + std::to_string(s.step) + ") differ");
+    if (failed_.empty() && s.step != hostStep_) throw std::runtime_error("the host's step count (" + std::to_string(hostStep_) + ") and the device's (" + std::to_string(s.step) + ") differ");
     double v[24];
     v[0] = s.engKin; v[1] = s.engVdW; v[2] = s.engCoul; v[3] = s.engElecField; v[4] = s.engTemp;
     for (int k = 0; k < 6; k++) { v[5 + k] = s.mom[k]; v[11 + k] = (double)s.cross[k]; }
@@ -1820,6 +1907,7 @@ void Engine::species_crossings(int64_t* out, int cap)
 {
     const int n = 6 * model_.nSpec();
     if (cap < n) throw std::runtime_error("species_crossings: output array too small");
+    settle();
     sync();
     DevStats s;
     HIP_CHECK(hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost));
@@ -1833,6 +1921,7 @@ void Engine::species_crossings(int64_t* out, int cap)
 // we put every atom back at its original index.  On several ranks each rank fills only the atoms it owns.
 void Engine::md_to_host(aztot_state& out)
 {
+    settle();
     sync();
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
@@ -1874,6 +1963,7 @@ void Engine::md_to_host(aztot_state& out)
 // restart support: step number + thermostat scalars (see aztot_clock)
 void Engine::get_clock(aztot_clock& out)
 {
+    settle();
     sync();
     DevStats s;
     HIP_CHECK(hipMemcpy(&s, dStats_, sizeof(DevStats), hipMemcpyDeviceToHost));
@@ -1882,6 +1972,7 @@ void Engine::get_clock(aztot_clock& out)
 
 void Engine::set_clock(const aztot_clock& in)
 {
+    settle();
     sync();
     snap_.valid = false;
     DevStats s;
@@ -1898,6 +1989,7 @@ void Engine::set_clock(const aztot_clock& in)
 // read-back of the sorted cell list (cudaMD::firstAtomInCell + the id of the atom in every slot)
 int Engine::cell_table(int32_t dims[3], int32_t* cellStart, int capCells, int32_t* atomId, int capAtoms)
 {
+    settle();
     sync();
     dims[0] = P_.ncxLocal; dims[1] = P_.nc[1]; dims[2] = P_.nc[2];
     const int nCell = P_.nCellLocal;
@@ -1919,6 +2011,8 @@ int Engine::cell_table(int32_t dims[3], int32_t* cellStart, int capCells, int32_
 // overwrite per-atom state (indexed by ORIGINAL atom id); used for exact restarts and stage-wise tests
 void Engine::set_state(const aztot_state& in)
 {
+    if (!failed_.empty()) throw std::runtime_error("this handle failed in an earlier call: " + failed_);
+    settle();
     sync();
     snap_.valid = false;
     sinceSort_ = 1 << 30; listsValid_ = false; carryAgreed_ = false;       // the next call rebuilds the cells

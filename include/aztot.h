@@ -212,6 +212,14 @@ void aztot_free_device(aztot_md *md);
 /* n iterations of the loop body of main.cu:281-410 (reset_quantities, verlet_1stage, iter_fastCellList,
    verlet_2stage, apply_tstat, calc_quantities) with the serial path's fp64 arithmetic */
 int aztot_step(aztot_md *md, int nsteps);
+/* aztot_step on ONE GPU may return with the kernels of its steps queued and the end of the call - the last step's second half-kick where it is folded into
+   the next step, the reduction of the statistics, the look at the cell-list rebuild schedule - still to come: every entry point that reads or writes state
+   (aztot_get_stats, aztot_md_to_host, aztot_get_clock, aztot_set_state, aztot_forces, ...) completes it first, so callers see no difference, and a caller
+   that steps one step at a time (the reference's loop is per step, main.cu:281-410, with a cudaThreadSynchronize behind every kernel) does not pay for a
+   synchronisation per step.  aztot_sync completes everything explicitly and returns when the device has finished: what a timed region ends with.  An error
+   detected only then is reported by the call that detects it.  After any error from aztot_step / aztot_sync the handle no longer steps (the first error is
+   repeated); reads still work for a post-mortem.  Slab ranks and runs with bonded terms end every call synchronously. */
+int aztot_sync(aztot_md *md);
 /* cell-list build + sort + pair forces for the current positions: iter_fastCellList (cuPairs.h:8) alone */
 int aztot_forces(aztot_md *md);
 int aztot_get_stats(aztot_md *md, aztot_stats *out);

@@ -14,7 +14,7 @@ import pytest
 
 from aztotmd_amd import api, inputs
 from oracle import oracle, parse
-from util import case_from_parsed, materialise_case_study, rel_err
+from util import FRC, VEL, case_from_parsed, materialise_case_study, per_atom_err, rel_err
 
 pytestmark = pytest.mark.gpu
 XVF = ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz")
@@ -74,6 +74,9 @@ def test_full_size_steps_match_the_serial_cpu_path(name):
         assert rel_err(s[k], ref[k]) < 1e-9, (name, who, k, rel_err(s[k], ref[k]))
     for k in ("fx", "fy", "fz"):
         assert rel_err(s[k], ref[k]) < 1e-11, (name, who, k, rel_err(s[k], ref[k]))
+    # ... and atom by atom: every one of the 1 000 188 forces (velocities) within 1e-9 of ITS OWN magnitude (floor: a thousandth of the rms)
+    assert per_atom_err(s, ref, FRC) < 1e-9, (name, who, per_atom_err(s, ref, FRC))
+    assert per_atom_err(s, ref, VEL) < 1e-9, (name, who, per_atom_err(s, ref, VEL))
     for k, v in eref.items():
         assert abs(st[k] - v) <= 1e-11 * abs(v) + 1e-12, (name, who, k, st[k], v)
     assert st["pairs_dropped"] == 0
@@ -282,6 +285,9 @@ def test_thermalised_liquid_at_full_size(name):
     assert 30.0 < st["temperature"] < 90.0, st["temperature"]
     for k in XVF:
         assert rel_err(s[k], ref[k]) < 1e-9, (name, who, k, rel_err(s[k], ref[k]))
+    # atom by atom (every force and velocity against its own magnitude), 18 steps into a thermal trajectory
+    assert per_atom_err(s, ref, FRC) < 1e-9, (name, who, per_atom_err(s, ref, FRC))
+    assert per_atom_err(s, ref, VEL) < 1e-9, (name, who, per_atom_err(s, ref, VEL))
     for k, v in eref.items():
         assert abs(st[k] - v) <= 1e-11 * abs(v) + 1e-12, (name, who, k, st[k], v)
     assert st["pairs_dropped"] == 0

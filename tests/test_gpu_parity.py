@@ -13,7 +13,7 @@ import pytest
 
 from aztotmd_amd import api, inputs
 from oracle import oracle
-from util import add_random_dynamics, family_with_coulomb, mixed_case, random_case, rel_err
+from util import FRC, VEL, add_random_dynamics, family_with_coulomb, mixed_case, per_atom_err, random_case, rel_err
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -33,6 +33,7 @@ def check_forces(case, tol=1e-11, **kw):
     s, st = e.state(), e.stats()
     for k in FKEYS:
         assert rel_err(s[k], so[k]) < tol, (k, rel_err(s[k], so[k]))
+    assert per_atom_err(s, so, FRC) < 1e-9, per_atom_err(s, so, FRC)        # every atom's force against its own magnitude (north star: 1e-9)
     assert abs(st["engVdW"] - sto["engVdW"]) <= 1e-12 * abs(sto["engVdW"]) + 1e-14
     assert abs(st["engCoul"] - sto["engElec3"]) <= 1e-12 * abs(sto["engElec3"]) + 1e-14
     return e, o
@@ -94,6 +95,10 @@ def test_golden_trajectory_F1():
         ref = dict(zip(EKEYS, z["e_%d" % st].tolist()))
         for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
             assert rel_err(s[k], z["%s_%d" % (k, st)]) < 1e-10, (st, k, rel_err(s[k], z["%s_%d" % (k, st)]))
+        zz = {k: z["%s_%d" % (k, st)] for k in FRC + VEL}
+        assert per_atom_err(s, zz, FRC) < 1e-9, (st, per_atom_err(s, zz, FRC))
+        if st:
+            assert per_atom_err(s, zz, VEL) < 1e-9, (st, per_atom_err(s, zz, VEL))
         assert abs(stt["engVdW"] - ref["engVdW"]) < 1e-12 * abs(ref["engVdW"])
         if st:
             assert abs(stt["engKin"] - ref["engKin"]) < 1e-11 * abs(ref["engKin"])
@@ -114,6 +119,8 @@ def test_golden_trajectory_4000(name, kw):
     ref = dict(zip(EKEYS, z["e_50"].tolist()))
     for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
         assert rel_err(s[k], z[k + "_50"]) < 1e-9, (k, rel_err(s[k], z[k + "_50"]))
+    zz = {k: z[k + "_50"] for k in FRC + VEL}
+    assert per_atom_err(s, zz, FRC) < 1e-9 and per_atom_err(s, zz, VEL) < 1e-9, (per_atom_err(s, zz, FRC), per_atom_err(s, zz, VEL))
     for a, b in (("engVdW", "engVdW"), ("engCoul", "engElec3"), ("engKin", "engKin"), ("engTot", "engTot")):
         assert abs(st[a] - ref[b]) <= 1e-11 * abs(ref[b]) + 1e-13, (a, st[a], ref[b])
 
@@ -817,10 +824,12 @@ def test_hip_path_against_the_reference_binary(name):
     s = e.state()
     for k in FKEYS:
         assert rel_err(s[k], d0[k]) < 1e-11, (name, k)
+    assert per_atom_err(s, d0, FRC) < 1e-9, (name, per_atom_err(s, d0, FRC))
     e.step(30)
     s, st = e.state(), e.stats()
     for k in ("x", "y", "z", "vx", "vy", "vz", "fx", "fy", "fz"):
         assert rel_err(s[k], d30[k]) < 1e-9, (name, k, rel_err(s[k], d30[k]))
+    assert per_atom_err(s, d30, FRC) < 1e-9 and per_atom_err(s, d30, VEL) < 1e-9, (name, per_atom_err(s, d30, FRC), per_atom_err(s, d30, VEL))
     for a, b in (("engVdW", "engVdW"), ("engCoul", "engElec3"), ("engKin", "engKin"), ("engTot", "engTot"), ("engBond", "engBond"),
                  ("engAngle", "engAngle"), ("engCoulRec", "engElec2"), ("engCoulConst", "engElec1")):
         assert abs(st[a] - d30[b]) <= 1e-10 * abs(d30[b]) + 1e-12, (name, a, st[a], d30[b])

@@ -10,6 +10,22 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
 
 
+def per_atom_err(a, b, keys=("fx", "fy", "fz"), floor=1e-3):
+    """The north star's "forces within 1e-9 relative" read atom by atom: max_i |dF_i| / max(|F_i|, floor * F_rms) over the vectors (a[k], b[k]).
+    rel_err scales by the LARGEST component of the whole array, which says nothing about an atom whose force is a hundred times smaller; here every
+    atom is measured against its own force (atoms whose force nearly vanishes - a lattice site - against a thousandth of the rms force)."""
+    d = np.sqrt(sum((np.asarray(a[k], dtype=float) - np.asarray(b[k], dtype=float)) ** 2 for k in keys))
+    mag = np.sqrt(sum(np.asarray(b[k], dtype=float) ** 2 for k in keys))
+    rms = float(np.sqrt((mag ** 2).mean()))
+    if rms == 0.0:
+        return float(d.max())
+    return float((d / np.maximum(mag, floor * rms)).max())
+
+
+VEL = ("vx", "vy", "vz")
+FRC = ("fx", "fy", "fz")
+
+
 def mixed_case(pot, n=5, a=5.6, seed=99, rc=7.0, vel_T=90.0):
     """Two-species liquid with the given potential family (same generator as the live-reference CPU test)."""
     base = inputs.lj_case((n, n, n), a=a, seed=seed, rc=rc, vel_T=vel_T, cell_list=rc)
