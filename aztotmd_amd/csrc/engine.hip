@@ -499,6 +499,9 @@ void Engine::allocate()
             const PairPot& p = model_.pot(a, b);
             DevPot& d = pots[(size_t)a * ns + b];
             d.type = p.type; d.use_radii = p.use_radii; d.p0 = p.p0; d.p1 = p.p1; d.p2 = p.p2; d.p3 = p.p3; d.p4 = p.p4; d.r2cut = p.r2cut;
+            // Lennard-Jones uses p0..p2 only (vdw.cpp:283-288: 4 eps, sigma^2, 24 eps); the two free slots carry the force law in powers of 1/r^2 for the
+            // one-species kernel (pair_body, MODE 1): f = u^4 (A2 u^3 - A1) with u = 1/r^2, A1 = 24 eps sigma^6, A2 = 48 eps sigma^12
+            if (p.type == AZTOT_VDW_LJ) { const double s6 = p.p1 * p.p1 * p.p1; d.p3 = p.p2 * s6; d.p4 = 2.0 * p.p2 * s6 * s6; }
         }
     {   // lazy re-sort: one GPU, no external field (its energy is booked from wrapped coordinates), not with pair kernel 3 (its bins are
         // rebuilt by the sort), a stencil that can be widened by one cell on a violation, and a slack worth having

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
         PairAcc acc = {0, 0, 0, 0, 0, 0};
         int nDropHalf = 0;
         const double ljDropR2 = P.ljDropR2;
-        const PairHot hot = kTab ? pair_hot_in_vgprs(P) : pair_hot(P);
+        const PairHot hot = kTab ? pair_hot_in_vgprs(P, lj) : (MODE == 1 ? pair_hot_lj_in_vgprs(P, lj) : pair_hot(P, lj));
         const int nChunks = (nIter + 7) >> 3;
         // software-pipelined: the candidate of iteration t + 1 is read from LDS before the potential of iteration t is evaluated (entries behind a lane's
         // last one point at the dummy - the builder fills the list buffer with it - so the read ahead is always a valid one)

@@ -83,12 +83,20 @@ constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-
 // The two wave-uniform numbers the table-driven bodies need in every visit.  The list kernel keeps them in VECTOR registers (pair_hot_in_vgprs): with the 31
 // polynomial coefficients of exp and erfc in scalar registers the compiler otherwise re-loads them from the kernel arguments inside the pair loop, and the
 // s_waitcnt lgkmcnt(0) that follows also waits for the LDS reads of the next candidate issued just before - the software pipelining was gone.
-struct PairHot { double r2Max, alpha; };
-__device__ __forceinline__ PairHot pair_hot(const StepParams& P) { return PairHot{P.r2Max, P.alpha}; }
-__device__ __forceinline__ PairHot pair_hot_in_vgprs(const StepParams& P)
+// ljA2 (one-species Lennard-Jones body): 48 eps sigma^12, the coefficient of the force polynomial's FMA - a vector register in the list kernel, because an FMA
+// takes ONE scalar operand and the other constant (-24 eps sigma^6) already is one: left to itself the compiler copied a constant into vector registers on every visit
+struct PairHot { double r2Max, alpha, ljA2; };
+__device__ __forceinline__ PairHot pair_hot(const StepParams& P, const DevPot& lj) { return PairHot{P.r2Max, P.alpha, lj.p4}; }
+__device__ __forceinline__ PairHot pair_hot_in_vgprs(const StepParams& P, const DevPot& lj)
 {
-    PairHot h{P.r2Max, P.alpha};
+    PairHot h{P.r2Max, P.alpha, lj.p4};
     asm volatile("" : "+v"(h.r2Max), "+v"(h.alpha));
+    return h;
+}
+__device__ __forceinline__ PairHot pair_hot_lj_in_vgprs(const StepParams& P, const DevPot& lj)
+{
+    PairHot h{P.r2Max, P.alpha, lj.p4};
+    asm volatile("" : "+v"(h.ljA2));
     return h;
 }
 
@@ -108,11 +116,17 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
         // (MASKED = the list kernel: an atom is never on its own list and idle lanes never meet the dummy candidate at r = 0, so r^2 > 0 needs no test)
         if ((MASKED || r2 > 0.0) & (r2 <= lj.r2cut))
         {
-            const double r2i = fast_rcp(r2);
-            const double sr2 = lj.p1 * r2i;
-            const double sr6 = sr2 * sr2 * sr2;
-            ra.eV = fma(0.5 * lj.p0, sr6 * (sr6 - 1.0), ra.eV);
-            double fm = lj.p2 * r2i * sr6 * (2.0 * sr6 - 1.0);
+            // fer_lj (vdw.cpp:16-26) computes sr2 = sigma^2 / r^2, sr6 = sr2^3, f = 24 eps / r^2 * sr6 * (2 sr6 - 1): seven multiplications behind the
+            // reciprocal.  The same polynomial in u = 1 / r^2 with the constants folded on the host (Engine::allocate: lj.p3 = 24 eps sigma^6,
+            // lj.p4 = 48 eps sigma^12) takes five - u^2, u^3, u^4, one FMA, one product -, each result within a few ulp of the reference's
+            // (the parity tests hold forces to 1e-11): 24 -> 22 vector instructions per visit of the list kernel
+            const double u = fast_rcp(r2);
+            const double u2 = u * u, u3 = u2 * u;
+            double fm = (u2 * u2) * fma(H.ljA2, u3, -lj.p3);
+            {   // energy (launches that book energies only: the compiler drops it elsewhere): 4 eps sr6 (sr6 - 1), sr6 = sigma^6 u^3
+                const double sr6 = (lj.p1 * lj.p1 * lj.p1) * u3;
+                ra.eV = fma(0.5 * lj.p0, sr6 * (sr6 - 1.0), ra.eV);
+            }
             // integrators.cpp:170-174: a pair with f^2 > 1e10 is dropped.  |f| grows monotonically as r shrinks below the minimum, so
             // the exact test is only reached (wave-uniform branch, practically never) when some lane is inside a generous radius
             if (__builtin_expect(__any(r2 < ljDropR2), 0))
@@ -360,7 +374,7 @@ __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable
             double radj = 0.0;
             if (MODE == 0 || MODE == 2 || MODE == 3 || MODE == 5) tj = ttyp[k];
             if (MODE == 0 || MODE == 4) radj = trad[k];
-            pair_body<MODE, VDW>(P, S, pots, lj, pairTab, live, dx, dy, dz, r2, ti, tj, radi, radj, ljDropR2, nDropHalf, ra, pair_hot(P));
+            pair_body<MODE, VDW>(P, S, pots, lj, pairTab, live, dx, dy, dz, r2, ti, tj, radi, radj, ljDropR2, nDropHalf, ra, pair_hot(P, lj));
             }
         } while (__any((cur | nxt | lst | ult) != 0u));
     }
