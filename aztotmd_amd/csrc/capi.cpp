@@ -227,6 +227,7 @@ static int init_device_common(const aztot_model* h, const aztot_options* opt, in
             return fail(AZTOT_ERR_ARG, "aztot_options.struct_size does not match this library (start from aztot_default_options)");
         o = *opt;
         for (int r : o.reserved) if (r != 0) return fail(AZTOT_ERR_ARG, "aztot_options.reserved must be zero");
+        if (o.pair_variant < 0 || o.pair_variant > 2) return fail(AZTOT_ERR_ARG, "aztot_options.pair_variant: 0 (automatic), 1 or 2 (variant 3 was retired: measured slower than 2)");
     }
     else aztot_default_options(&o);
     return guarded([&] {

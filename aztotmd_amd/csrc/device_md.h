@@ -20,18 +20,6 @@ struct AtomArrays
     int32_t *id;                  // persistent atom id (ours: stable key for RNG / output order / determinism)
 };
 
-// Fixed-size bins of 16 atoms per cell, written by the sort next to the per-atom arrays and read by pair kernel 3 (pair_quad.hip.h):
-// cell c owns the bins c * perCell .. c * perCell + perCell - 1, of which the first ceil(count / 16) are in use; coordinates are relative
-// to the centre of the atom's own cell, the unused slots of the last bin in use hold far-away dummies.  A tile of the pair kernel is then a
-// list of whole bins: aligned 16-entry copies, no compaction, no per-atom bookkeeping; a neighbour cell's image shift is a multiple of the
-// cell edge, whatever the periodic wrap.  (The reference re-reads neighbours atom by atom from global memory, cuPairs.cu:1474-1625.)
-struct CellBins
-{
-    double *x, *y, *z;            // [nCellLocal * perCell * 16]; x == nullptr: not in use
-    int32_t* type;
-    int32_t perCell;              // bins reserved per cell; atoms beyond 16 * perCell of a cell are read from the per-atom arrays instead
-};
-
 // reference positions of the lazy re-sort: where every atom was when the cells were last rebuilt (sorted order); x == nullptr: not in use
 struct RefPos { double *x, *y, *z; };
 

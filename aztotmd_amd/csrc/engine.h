@@ -58,6 +58,57 @@ enum DebugBit : unsigned
     DBG_SETTLE_EVERY_CALL = 268435456    // every aztot_step call ends with the look / statistics / synchronisation (one GPU defers them to the next look or read)
 };
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// The host state machine in one table.  "Forget" = the three assignments `sinceSort_ = 1 << 30; listsValid_ = false;
+// carryAgreed_ = false` that make the next step rebuild the cells.  API calls that touch state first complete a deferred call end (Engine::settle).
+//
+//  member            meaning                                              set by                                      cleared / reset by                         invalidated by (API)
+//  ----------------  ---------------------------------------------------  ------------------------------------------  -----------------------------------------  ---------------------------------------
+//  unsettled_        the last aztot_step returned before its end           step_body (every call)                      settle (at once when settle_now(), else     every read / write entry point settles
+//                    (deferred kick, statistics, look) had happened                                                    by the next reader or the next due look)    first; mark_failed drops it
+//  failed_           first error of a step / settle: no more stepping      mark_failed                                 never (the handle is dead for stepping)    -
+//  hostStep_         steps launched so far (== DevStats::step when the     launch_step_kernels (+1), run_steps (graph  replay_from_snapshot (snapshot's),          aztot_set_clock; mark_failed re-reads it
+//                    stream has drained)                                   replay: + cycle)                            set_clock                                  from the device
+//  lazyK_            sort interval in force (1: every step)                adapt_sort_interval (from the longest step  -> 1: set_state with new v / f, a slab      aztot_set_state (v, f); aztot_forces keeps it
+//                                                                          seen), constructor (debug: fixed)           violation (replay), never above lazyCap_
+//  lazyMeasured_     lazyK_ comes from a measurement                       adapt_sort_interval                         set_state (v, f), slab violation            aztot_set_state (v, f)
+//  lazyWindow_       steps between two looks: 8, 16 ... 256 (64 on slabs)  step_body / settle (doubling)               -> 8: set_state (v, f), slab violation      aztot_set_state (v, f)
+//  sinceLook_        steps since the last look (runs on across calls)      step_body (+ n)                             every look (-> 0); set_state (v, f)         aztot_set_state (v, f)
+//  lazyMargin_       K steps of the longest step may use slack / margin    adapt_sort_interval (x 4/3 per violation)   never shrinks                               -
+//  sinceSort_        plain steps since the last rebuild (1 << 30: none)    sort_and_forces (0 at a rebuild, +1 plain)  Forget                                      aztot_forces, aztot_set_state, aztot_set_clock,
+//                                                                                                                                                                  replay, list re-allocation, run_steps without carryOn
+//  listsValid_       the lists on the device are those of the arrays as    launch_pair (build), prepare_next_call      Forget; sort_and_forces until launch_pair   as sinceSort_
+//                    they stand (a call may open with plain steps)                                                     has recorded the new ones; free_lists
+//  listsOn_          lists exist and plain steps walk them                 allocate_lists                              free_lists; adapt_sort_interval when most   -
+//                                                                                                                      unlisted cells can never be listed
+//  candLds_/iterLds_ LDS sizes of k_pair_list / k_build_lists              allocate_lists (= capacities)               adapt_sort_interval, prepare_next_call      - (baked into graphs: destroy_graphs)
+//                                                                                                                      (tightened to the largest cell recorded)
+//  unlistedState_    cells without a list in the lists in force: 0 ?,      launch_pair (slab: read back behind the     launch_pair at every build (-> 0), replay    -
+//                    1 none, 2 some                                        build), prepare_next_call
+//  unlistedAtLook_   the last look found cells recorded without a list     adapt_sort_interval                         the next look that saw a recording          -
+//  carryAgreed_      slab ranks: all agreed the next call may open with    prepare_next_call (all-reduce)              Forget                                      as sinceSort_
+//                    plain steps
+//  optimistic_       plain steps run without the clean-up launch           choose_optimism (start of a settled call,   choose_optimism; replay_from_snapshot       - (P_.optimistic is baked into graphs)
+//                    (P_.optimistic)                                       after every look)
+//  safeLooks_        looks still to spend with the clean-up launch         constructor (1), replay (4 << rollbacks_)   every look (- 1)                            -
+//  snap_.valid       a verified snapshot of the dynamic state exists       take_snapshot (start of a settled call,     choose_optimism (not optimistic any more),  aztot_forces, aztot_set_state, aztot_set_clock,
+//                                                                          every clean look; kept when younger than    settle (no roll-back mode)                  mark_failed
+//                                                                          kSnapshotKeepSteps)
+//  stepsSinceSnap_   steps launched since the snapshot                     step_body (+ n), replay (= n)               take_snapshot (-> 0)                        -
+//  kickOwed_         the last step's second half-kick has not been         step_body (= lazyKick_ at the end of a      finish_steps (k_integrate2); start of the   -
+//                    applied and settle must apply it                      call), replay                               next step_body (the device flag
+//                                                                                                                      DevStats::pendingKick makes the next
+//                                                                                                                      integrate kernel pay it)
+//  preIntegrated_    the step being launched was opened by the previous    launch_pair (next-step fusion),             sort_and_forces (consumes it), run_steps,   -
+//                    step's pair kernel / boundary kernel                  launch_step_kernels (k_boundary_radi)       graph capture, replay
+//  fuseNext_/fuseNow_/pairClosedStep_/overlapHalo_/candMode_/stepsLeftInRun_   per-launch scratch: set and consumed inside launch_step_kernels / launch_pair
+//  graphs_, graphCycle_  captured cycles, valid for one buffer state and   graph_for_state                             destroy_graphs: any change of lazyK_,        aztot_set_clock, aztot_set_state (U / radius
+//                    one set of launch parameters                                                                       optimistic_, candLds_ / iterLds_,          first touched), replay
+//                                                                                                                      listWaves_, listsOn_, thermoTouched_
+//  haloInfoPending_  slab: the boundary ranges of the last sort are still  sort_and_forces                             take_halo_info, prepare_next_call, replay   -
+//                    on their way to pinned memory
+//  lastStepEquil_    the last step left its kinetic energy in DevStats     launch_step_kernels                         launch_step_kernels                         -
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
 class Engine
 {
 public:
@@ -192,7 +243,6 @@ private:
     void post_count_exchange();
     void adopt_halo_info(const int32_t* h);
     int graphCycle_ = 0;            // steps held by the captured graphs
-    CellBins bins_{};               // per-cell bins of 16 atoms for pair kernel 3 (all-null when that kernel cannot run)
     BondedTables bonded_{};         // all-null when the model has no bonds / angles
     bool hasBonded_ = false;
     bool thermoTouched_ = false;    // the caller set U / radius on a run whose model does not use them: keep them attached to their atoms

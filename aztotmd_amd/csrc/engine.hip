@@ -16,7 +16,6 @@
 #include "kernels.hip.h"
 #include "pair_tile.hip.h"
 #include "pair_list.hip.h"
-#include "pair_quad.hip.h"
 #include "slab.hip.h"
 
 namespace aztot {
@@ -100,7 +99,7 @@ void Engine::choose_cells()
     // nothing at all on a box of 42 x 8.5 A) the cells are sized rc + skin instead; "edge >= the requested size" still holds.  Deliberately finer or
     // coarser grids are left alone (their stencil reach is what it is).
     skinTarget_ = 0.0;
-    const bool lazyWanted = opt_.sort_every != 1 && opt_.pair_variant != 3 && m.rMax > 0 && m.E[0] == 0.0 && m.E[1] == 0.0 && m.E[2] == 0.0 && opt_.skin >= 0.0;
+    const bool lazyWanted = opt_.sort_every != 1 && m.rMax > 0 && m.E[0] == 0.0 && m.E[1] == 0.0 && m.E[2] == 0.0 && opt_.skin >= 0.0;
     if (lazyWanted)
     {
         const double skin = opt_.skin > 0.0 ? opt_.skin : std::min(0.5, std::max(0.15, 0.036 * m.rMax));
@@ -503,8 +502,8 @@ void Engine::allocate()
             // one-species kernel (pair_body, MODE 1): f = u^4 (A2 u^3 - A1) with u = 1/r^2, A1 = 24 eps sigma^6, A2 = 48 eps sigma^12
             if (p.type == AZTOT_VDW_LJ) { const double s6 = p.p1 * p.p1 * p.p1; d.p3 = p.p2 * s6; d.p4 = 2.0 * p.p2 * s6 * s6; }
         }
-    {   // lazy re-sort: one GPU, no external field (its energy is booked from wrapped coordinates), not with pair kernel 3 (its bins are
-        // rebuilt by the sort), a stencil that can be widened by one cell on a violation, and a slack worth having
+    {   // lazy re-sort: no external field (its energy is booked from wrapped coordinates), a stencil that can be widened by one cell on a violation
+        // (one GPU), and a slack worth having
         const Model& m = model_;
         double slack = 1e300;
         bool widenOk = true;
@@ -516,7 +515,7 @@ void Engine::allocate()
         const int sortEvery = opt_.sort_every;                    // 0: adaptive, 1: every step (the reference's schedule), n: at most every n-th step
         // (a slab rank cannot widen its stencil - it holds hw ghost layers -: there a violation is repaired by going back to the last look's snapshot and
         //  running the window again with the cells rebuilt every step, Engine::replay_from_snapshot; the interval keeps a factor 2 in hand)
-        lazyOn_ = sortEvery != 1 && opt_.pair_variant != 3 && (widenOk || nranks_ > 1) && m.rMax > 0 && slack > 1e-3 && m.E[0] == 0.0 && m.E[1] == 0.0 &&
+        lazyOn_ = sortEvery != 1 && (widenOk || nranks_ > 1) && m.rMax > 0 && slack > 1e-3 && m.E[0] == 0.0 && m.E[1] == 0.0 &&
                   m.E[2] == 0.0 && pair_tile_supported(P_);
         lazyCap_ = sortEvery > 1 ? std::min(sortEvery, kLazyCapMax) : kLazyCapMax;
         if (lazyOn_ && (debug_ & 8192)) lazyK_ = lazyCap_;
@@ -575,18 +574,6 @@ void Engine::allocate()
                     free_lists();
                 }
             }
-        }
-    }
-    {   // bins for pair kernel 3: only where it can run (stencil half-width 1, a specialised potential set, moderate density)
-        const bool specialised = P_.single_lj || P_.pad1 == 2;
-        const int perCell = pair_quad_bins_per_cell((double)capacity_ / std::max(1, P_.nCellLocal));
-        // opt-in (pair_variant 3): measured on the 1 M-atom box it is 8 % SLOWER than the one-wave tile kernel
-        if (opt_.pair_variant == 3 && specialised && pair_quad_supported(P_) && pair_quad_density_ok(perCell))
-        {
-            const size_t nSlots = (size_t)P_.nCellLocal * perCell * 16;
-            bins_.perCell = perCell;
-            bins_.x = (double*)alloc(sizeof(double) * nSlots); bins_.y = (double*)alloc(sizeof(double) * nSlots); bins_.z = (double*)alloc(sizeof(double) * nSlots);
-            bins_.type = (int32_t*)alloc(sizeof(int32_t) * nSlots);
         }
     }
     dPots_ = (DevPot*)alloc(sizeof(DevPot) * pots.size());
@@ -874,14 +861,13 @@ void Engine::upload_initial()
 // ---------------------------------------------------------------------------------------------------
 // pair kernel dispatch
 // ---------------------------------------------------------------------------------------------------
-// which pair kernel runs: 1 per-atom gather (any geometry), 2 one wave per cell with its own LDS tile, 3 four waves share the tile of
-// four z-consecutive cells (cell edge >= cut-off, no generic potential mix).  0 = the best one that supports the system
+// which pair kernel runs: 1 per-atom gather (any geometry), 2 one wave per cell with its own LDS tile (+ the pair lists of the lazy re-sort).
+// 0 = the best one that supports the system.  (Round 2's variant 3 - four waves sharing a tile of 16-atom cell bins, measured 8 % slower than 2 - was
+// retired in round 4: NOTES.md.)
 int Engine::pair_variant() const
 {
-    const bool quadOk = bins_.x != nullptr;          // allocate(): geometry, potential set and density allow k_pair_quad
     int variant = opt_.pair_variant;
-    if (variant == 0) variant = quadOk ? 3 : (pair_tile_supported(P_) ? 2 : 1);
-    if (variant == 3 && !quadOk) variant = 2;
+    if (variant == 0) variant = pair_tile_supported(P_) ? 2 : 1;
     if (variant == 2 && !pair_tile_supported(P_)) variant = 1;
     return variant;
 }
@@ -889,13 +875,7 @@ int Engine::pair_variant() const
 void Engine::launch_pair()
 {
     const int variant = pair_variant();
-    if (variant == 3)
-    {
-        StepParams Q = P_;
-        Q.fuseKick = fuseNow_ ? 1 : 0;
-        timed("pair_quad", [&] { launch_pair_quad(Q, S_, dPots_, cur(), bins_, dCounts_, dCellStart_, dPartials_, maxBlocks_, stream_); });
-    }
-    else if (variant == 2)
+    if (variant == 2)
     {
         StepParams Q = P_;
         Q.fuseKick = fuseNow_ ? 1 : 0;
@@ -985,7 +965,7 @@ void Engine::launch_pair()
                                dCellOfSorted_, dPartials_, maxBlocks_);
         });
     if (variant < 2) fuseNow_ = false;           // only the tile kernels have the fused epilogue (cannot happen: see the constructor)
-    pairBlocksUsed_ = (variant == 3) ? pair_quad_grid(P_) : (variant == 2) ? (splitBlocks_ ? splitBlocks_ : pair_tile_grid(P_) * split_.n) : div_up(capacity_, kBlock);
+    pairBlocksUsed_ = (variant == 2) ? (splitBlocks_ ? splitBlocks_ : pair_tile_grid(P_) * split_.n) : div_up(capacity_, kBlock);
     blocksEver_ = std::max(blocksEver_, std::max(pairBlocksUsed_, div_up(capacity_, kBlock)) + 1);
 }
 
@@ -1118,7 +1098,7 @@ void Engine::sort_and_forces(int stepMode, bool withBonded)
     });
     timed("rank_gather", [&] {
         hipLaunchKernelGGL(k_rank_gather, dim3(gridAtoms), dim3(kBlock), 0, stream_, dCounts_, dCellStart_, dTmpId_, dTmpSrc_, dTmpCell_, cur(), oth(),
-                           dCellOfSorted_, (P_.tstat == AZTOT_TSTAT_RADI || P_.use_radii || thermoTouched_) ? 2 : 0, P_, dCounts_, bonded_.idxOfId, bins_, ref_,
+                           dCellOfSorted_, (P_.tstat == AZTOT_TSTAT_RADI || P_.use_radii || thermoTouched_) ? 2 : 0, P_, dCounts_, bonded_.idxOfId, ref_,
                            dHaloInfo_, (listsOn_ && stepMode == 1 && lazyOn_ && lazyK_ > 1) ? dNoList_ + 2 : nullptr, listsOn_ ? dRel_ : nullptr);
     });
     cur_ ^= 1;
@@ -1388,14 +1368,14 @@ void Engine::step(int nsteps)
     catch (...) { mark_failed("unknown exception"); throw; }
 }
 
-// Does this call end with the look / statistics / read-backs right away?  Slab ranks (collectives every rank must take together), bonded terms and pair
-// kernel 3 (overflow flags to read back), per-kernel timing (events to drain): always.  One GPU otherwise: only when a look at the sort interval is due
+// Does this call end with the look / statistics / read-backs right away?  Slab ranks (collectives every rank must take together), bonded terms
+// (an overflow flag to read back), per-kernel timing (events to drain): always.  One GPU otherwise: only when a look at the sort interval is due
 // (8, 16, ... 256 steps after the last one, or never made) - else the call returns with its kernels queued, and whoever reads state or statistics next
 // (or the next look) settles: a caller that steps one step at a time (the reference's loop is per step, main.cu:281-410) pays for the second half-kick
 // launch, the statistics reduction, the stream synchronisation and the snapshot once per look instead of once per step.
 bool Engine::settle_now() const
 {
-    if (nranks_ > 1 || hasBonded_ || profile_ || pair_variant() == 3 || (debug_ & DBG_SETTLE_EVERY_CALL)) return true;
+    if (nranks_ > 1 || hasBonded_ || profile_ || (debug_ & DBG_SETTLE_EVERY_CALL)) return true;
     if (!lazyOn_) return false;
     return !lazyMeasured_ || sinceLook_ >= lazyWindow_;
 }
@@ -1840,13 +1820,10 @@ bool Engine::adapt_sort_interval()
 
 void Engine::check_overflow()
 {
-    const bool quad = pair_variant() == 3;
-    if (nranks_ <= 1 && !hasBonded_ && !quad) return;
+    if (nranks_ <= 1 && !hasBonded_) return;
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
-    if (c.overflow && nranks_ <= 1)
-        throw std::runtime_error("pair kernel 3: the six cells of one z-column do not fit its LDS tile (> 170 atoms per cell locally); use pair_variant 2");
-    if (c.overflow) throw std::runtime_error("slab decomposition: a fixed-capacity halo/migration/atom buffer overflowed (or pair kernel 3's LDS tile)");
+    if (c.overflow) throw std::runtime_error("slab decomposition: a fixed-capacity halo/migration/atom buffer overflowed");
     if (c.bondedMissing)
         throw std::runtime_error("slab decomposition: a bond / angle partner was not resident on the rank that owns the atom "
                                  "(bonded terms must span less than the halo width)");

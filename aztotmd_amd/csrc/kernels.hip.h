@@ -753,7 +753,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
                                                         const int32_t* __restrict__ tmpId, const int32_t* __restrict__ tmpSrc,
                                                         const int32_t* __restrict__ tmpCell, AtomArrays src, AtomArrays dst,
                                                         int32_t* __restrict__ cellOfSorted, int carryForces /* bit 0: forces, bit 1: U + radius */, StepParams P, Counts* cntOut,
-                                                        int32_t* __restrict__ idxOfId, CellBins B, RefPos R0, int32_t* __restrict__ haloInfo,
+                                                        int32_t* __restrict__ idxOfId, RefPos R0, int32_t* __restrict__ haloInfo,
                                                         int32_t* __restrict__ zeroMe, float4* __restrict__ rel)
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
@@ -798,25 +798,6 @@ __global__ __launch_bounds__(kBlock) void k_rank_gather(const Counts* __restrict
         const double cy = cell_coord(y, P.icsz[1], P.nc[1]) * P.csz[1] + 0.5 * P.csz[1];
         const double cz = gz * P.csz[2] + 0.5 * P.csz[2];
         rel[d] = make_float4((float)(x - cx), (float)(y - cy), (float)(z - cz), (float)gz);
-    }
-    if (B.x)
-    {   // the same atom in its cell's bins, relative to the centre of the cell it was binned into (count_cell: floor(x * cRevSize))
-        if (rank < 16 * B.perCell)
-        {
-            const int t = src.type[i];
-            const double cx = cell_coord(x, P.icsz[0], P.nc[0]) * P.csz[0] + 0.5 * P.csz[0];
-            const double cy = cell_coord(y, P.icsz[1], P.nc[1]) * P.csz[1] + 0.5 * P.csz[1];
-            const double cz = cell_coord(z, P.icsz[2], P.nc[2]) * P.csz[2] + 0.5 * P.csz[2];
-            const size_t g = ((size_t)c * B.perCell) * 16 + rank;
-            B.x[g] = x - cx; B.y[g] = y - cy; B.z[g] = z - cz; B.type[g] = t;
-            if (rank == e - s - 1)
-                for (int q = rank + 1; q & 15; q++)
-                {   // far-away, finite dummies behind the last atom of the cell, up to the end of its last bin
-                    const size_t gq = ((size_t)c * B.perCell) * 16 + q;
-                    B.x[gq] = -1e30; B.y[gq] = 0.0; B.z[gq] = 0.0; B.type[gq] = 0;
-                }
-        }
-        // atoms beyond the cell's bins (rank >= 16 perCell) are staged by the pair kernel from the per-atom arrays
     }
     dst.vx[d] = src.vx[i]; dst.vy[d] = src.vy[i]; dst.vz[d] = src.vz[i];
     if (carryForces & 2) { dst.U[d] = src.U[i]; dst.rad[d] = src.rad[i]; }     // thermostat state: only when something reads it

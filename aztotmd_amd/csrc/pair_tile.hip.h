@@ -325,7 +325,7 @@ __device__ __forceinline__ void tile_filter(const double* tx, const double* ty, 
 }
 
 // The two passes over one staged chunk.  NW: 32-candidate mask words per round (3 for the one-wave tile of <= 320 candidates, 4 for the shared tile of
-// k_pair_quad whose windows hold ~400)
+// a retired kernel whose windows held ~400)
 template <int MODE, int VDW, int LG, int STRIDE = kTileLds, int NW = 3>
 __device__ __forceinline__ void tile_passes(const StepParams& P, const SpecTable& S, const DevPot* __restrict__ pots, const DevPot& lj,
                                             const double* tx, const double* ty, const double* tz, const float* tw, const uint8_t* ttyp, const double* trad,

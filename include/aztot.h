@@ -131,8 +131,7 @@ typedef struct
                                        sys_init.cpp:1181-1184); 0: start from F = 0 (GPU path, sys_init.cpp:551-553) */
     int32_t center_box;          /* 1: apply center_box at init (serial path only, sys_init.cpp:1145) */
     uint64_t seed;               /* seed of the counter-based RNG (thermostat, tables, init_vel) */
-    int32_t pair_variant;        /* 0: auto (= 2 where the geometry allows, else 1); 1: per-atom gather kernel; 2: LDS-tiled wave-per-cell kernels (+ pair lists);
-                                    3: four waves share a tile of 16-atom cell bins (opt-in: slower than 2 on MI355X) */
+    int32_t pair_variant;        /* 0: auto (= 2 where the geometry allows, else 1); 1: per-atom gather kernel; 2: LDS-tiled wave-per-cell kernels (+ pair lists) */
     double cell_size;            /* 0: derive from control.cell_list / cut-off (+ skin); >0: force this cell edge */
     int32_t use_graph;           /* 1: replay the step as a captured hipGraph when possible */
     int32_t profile;             /* 1: time every kernel with HIP events (aztot_kernel_times) */
