@@ -134,9 +134,9 @@ def test_slabs_with_per_atom_kernel():
 
 
 @pytest.mark.parametrize("name,nranks,port", [("lj", 2, 29621), ("fennel", 3, 29622)])
-def test_slabs_with_shared_tile_kernel(name, nranks, port):
-    """pair_variant 3 (four waves share a tile of cell bins; opt-in) on slab ranks: ghost layers are binned like owned ones"""
-    out = run_ranks(nranks, name, 15, extra={"pair_variant": 3}, port=port)
+def test_slabs_with_the_per_atom_kernel(name, nranks, port):
+    """pair_variant 1 (one thread per atom, any geometry: the fallback where no cell tile fits) on slab ranks: ghosts are read like owned atoms"""
+    out = run_ranks(nranks, name, 15, extra={"pair_variant": 1}, port=port)
     assert out["every_atom_owned_once"] and out["max_rel_err_vs_single"] < 1e-9, out["errs"]
 
 
