@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <string>
@@ -208,7 +209,8 @@ private:
     long long lazyViolations_ = 0;
     int lazyWindow_ = 8;               // steps between two looks at the speeds: 8, 16, ... 256
     int sinceLook_ = 0;                // steps since the last look (runs on across calls)
-    double lazyMargin_ = 1.3;          // one GPU: K steps of the longest step seen may use slack / lazyMargin_; widened by every violation (a system that heats up)
+    double lazyMargin_ = 1.15;         // one GPU: K steps of the longest step seen may use slack / lazyMargin_ (1.3 until round 4: 20 000 steps of C4T and 10 000 of C3T run
+                                       // without a violation at 1.05 too); widened by every violation (a system that heats up)
     bool lazyMeasured_ = false;     // the interval has been sized from a measurement at least once
     int sinceSort_ = 1 << 30;       // plain steps since the last sort
     long long rebuilds_ = 0;        // steps that rebuilt the cell list so far
@@ -278,7 +280,13 @@ private:
     // (which AtomArrays is current, which coordinate arrays each of them holds: the sort ping-pongs the buffers, the fused next-step epilogue swaps
     // coordinate arrays); it also remembers the state it leaves behind
     struct BufState { int cur; double* xyz[2][3]; double* alt[2][3]; };
-    struct GraphSlot { BufState before, after; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    // ... and what the host notes down while it launches a step for whoever reduces the statistics afterwards (finish_steps): a replayed cycle does not pass
+    // through that host code, so the slot carries the notes of its last step (found by the call-pattern fuzz of round 4: aztot_forces - whose staging launch
+    // books into more partial-sum slots than the list kernel - followed by a call served entirely by replays summed stale slots into the energies)
+    struct LaunchNotes { int pairBlocksUsed = 0, blocksEver = 0; bool ekinFromPair = false, lastStepEquil = false; };
+    struct GraphSlot { BufState before, after; LaunchNotes notes; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    LaunchNotes launch_notes() const { LaunchNotes n; n.pairBlocksUsed = pairBlocksUsed_; n.blocksEver = blocksEver_; n.ekinFromPair = ekinFromPair_; n.lastStepEquil = lastStepEquil_; return n; }
+    void adopt_launch_notes(const LaunchNotes& n) { pairBlocksUsed_ = n.pairBlocksUsed; blocksEver_ = std::max(blocksEver_, n.blocksEver); ekinFromPair_ = n.ekinFromPair; lastStepEquil_ = n.lastStepEquil; }
     std::vector<GraphSlot> graphs_;
     BufState buf_state() const;
     GraphSlot* graph_for_state(int cycle);

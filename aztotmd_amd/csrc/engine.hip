@@ -183,6 +183,7 @@ void Engine::construct()
     profile_ = opt_.profile != 0;
     if (const char* dbg = std::getenv("AZTOT_DEBUG")) debug_ = (unsigned)std::strtoul(dbg, nullptr, 0);
     if (opt_.energies_every_step) debug_ |= DBG_ENERGIES_EVERY_STEP;
+    if (const char* e = std::getenv("AZTOT_MARGIN")) lazyMargin_ = std::max(1.0, std::atof(e));      // (experiments: K steps of the longest step seen may use slack / margin)
     if (nranks_ > 1 && !xch_ && !opt_.loopback_ranks) throw std::runtime_error("slab decomposition needs an exchanger");
 
     const Model& m = model_;
@@ -1509,6 +1510,7 @@ Engine::GraphSlot* Engine::graph_for_state(int cycle)
     GraphSlot g;
     g.before = now;
     const int sinceBefore = sinceSort_;
+    const LaunchNotes notesBefore = launch_notes();      // (the capture executes nothing: what the host knows about the last EXECUTED step must survive it)
     HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
     capturing_ = true;
     try
@@ -1526,13 +1528,16 @@ Engine::GraphSlot* Engine::graph_for_state(int cycle)
         preIntegrated_ = false;
         sinceSort_ = sinceBefore;
         set_buf_state(now);
+        adopt_launch_notes(notesBefore);
         throw;
     }
     capturing_ = false;
     HIP_CHECK(hipStreamEndCapture(stream_, &g.graph));
     HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
     g.after = buf_state();
+    g.notes = launch_notes();         // ... of the cycle's last step
     set_buf_state(now);               // the capture itself executed nothing
+    adopt_launch_notes(notesBefore);
     sinceSort_ = sinceBefore;
     stepsLeftInRun_ = 0;
     graphs_.push_back(g);
@@ -1545,7 +1550,7 @@ void Engine::run_steps(int nsteps)
     // Lazy re-sort (one GPU): the reference rebuilds its cell list every step (main.cu:300-326); here a step re-sorts only every lazyK_-th time.  That is
     // exact as long as no atom is farther than (stencil reach - rc) / 2 from where it was when the cells were built: every pair inside rc is then still
     // found in the stencil of the cell the atoms were sorted into.  Plain steps leave slots, cells and buffers alone, keep coordinates unwrapped, count
-    // wall crossings when they happen, and check every atom's displacement; should one ever leave the slack (the interval is sized with a factor 1.3 to
+    // wall crossings when they happen, and check every atom's displacement; should one ever leave the slack (the interval is sized with a factor 1.15 to
     // spare from the largest step seen), the pair kernels reach one cell further until the next sort - slower, still exact.  The first step of
     // every call sorts (the deferred half-kick is re-armed by the scan).
     // With pair lists a sort interval runs on from the previous call when nothing has touched the state since (the lists are those of the arrays as they
@@ -1567,6 +1572,7 @@ void Engine::run_steps(int nsteps)
             hostStep_ += cycle;
             rebuilds_ += (lazyOn_ && lazyK_ > 1) ? 1 : cycle;       // (a captured cycle: one sort interval, or two every-step steps)
             set_buf_state(slot->after);           // one sort per cycle (K > 1) and the coordinate-array swaps of the fused steps
+            adopt_launch_notes(slot->notes);      // where the cycle's last step left its partial sums
             sinceSort_ = 1 << 30;                 // the next cycle (or the eager remainder) starts with a sort
         }
     }
@@ -1645,7 +1651,7 @@ void Engine::prepare_next_call()
     if (can_graph()) (void)graph_for_state(graph_cycle());
 }
 
-// the largest step any atom made since the last look sizes the next calls' sort interval: K steps of that length use at most slack / 1.3 (Engine::lazyMargin_)
+// the largest step any atom made since the last look sizes the next calls' sort interval: K steps of that length use at most slack / 1.15 (Engine::lazyMargin_)
 // (one GPU; a violation is handled exactly by the clean-up launch at the staging kernel's speed, so the margin is a performance choice: with half the
 // slack C4 ran at K = 16, with two thirds at K = 24-28, no violation in 2 000 steps; every violation widens the margin for good - a system that heats up,
 // like the Born-Mayer-Huggins melt B3, would otherwise run into one after the other) - half on slab ranks, whose repair (a window of steps run again) is dearer.
@@ -1787,7 +1793,7 @@ bool Engine::adapt_sort_interval()
             const int32_t z = 0;
             HIP_CHECK(hipMemcpy(&dCounts_->lazyViolatedEver, &z, sizeof(z), hipMemcpyHostToDevice));
             lazyViolations_++;
-            lazyMargin_ = std::min(4.0, lazyMargin_ * (4.0 / 3.0));      // the speeds are growing: more room from now on (1.3 -> 1.7 -> 2.3 -> 3.1 -> 4)
+            lazyMargin_ = std::min(4.0, lazyMargin_ * (4.0 / 3.0));      // the speeds are growing: more room from now on (1.15 -> 1.5 -> 2.0 -> 2.7 -> 3.6 -> 4)
         }
         int fromSpeed = -1;
         if (c.maxStep2 != 0)

@@ -148,6 +148,29 @@ def test_deferred_end_of_call_is_bit_identical(name):
         assert np.array_equal(a.state()[k], b.state()[k], equal_nan=True), (name, k)
 
 
+@pytest.mark.parametrize("name", ["liquid", "fennell"])
+def test_statistics_after_a_call_served_entirely_by_replayed_cycles(name):
+    """Found by the fuzz above (round 4): aztot_forces launches the staging kernel, which books its energies into more partial-sum slots than the list
+    kernel; a following call made of whole replayed cycles (hipGraphs: no host code per step) then summed those stale slots into the statistics. A graph slot
+    now carries the host's notes of its last step (Engine::LaunchNotes)."""
+    case = systems(name)
+    a = api.Engine(api.Model.from_case(case), sort_every=8, debug=FIXED_INTERVAL)
+    b = api.Engine(api.Model.from_case(case), sort_every=1)
+    for e in (a, b):
+        e.step(8)
+        e.step(16)              # (the cycles are captured by now)
+        e.forces()              # k_pair_tile: several waves per cell, each with a slot of its own
+        e.step(32)              # four whole cycles of 8: replays only
+    sa, sb = a.stats(), b.stats()
+    assert sa["step"] == sb["step"] == 56
+    for k in ("engTot", "engKin", "engVdW", "engCoul"):
+        if abs(sb[k]) > 0:
+            assert abs(sa[k] - sb[k]) <= 1e-9 * abs(sb[k]), (name, k, sa[k], sb[k])
+    xa, xb = a.state(("x", "vx", "fx")), b.state(("x", "vx", "fx"))
+    for k in ("x", "vx", "fx"):
+        assert rel_err(xa[k], xb[k]) < 1e-9, (name, k)
+
+
 def stress_case(seed):
     """tools/stress_repair.py's systems: a lattice of five to nine cells of rc + skin per axis, hot enough to leave the slack within the held interval;
     every third with Fennell charges, every third dense enough for nearest neighbours to be bonded; random thermostat / equilibration schedule on top"""
