@@ -128,46 +128,51 @@ __device__ __forceinline__ double fast_rcp(double x)
     return fma(y, fma(e, e, e), y);              // four of two Newton steps
 }
 
-// 1/sqrt(x): v_rsq_f64 refined by two Newton steps (y += y/2 (1 - x y^2)); 9 instructions for what gives r = x y, 1/r = y and
+// 1/sqrt(x): v_rsq_f64 refined (below); 6 instructions for what gives r = x y, 1/r = y and
 // 1/r^2 = y y, instead of the reciprocal above plus ocml's range-scaled sqrt.  x is a squared distance: normal, positive.
 __device__ __forceinline__ double fast_rsqrt(double x)
 {
-    double y = __builtin_amdgcn_rsq(x);
-    y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
-    y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
-    return y;
+    // one third-order step y (1 + e/2 + 3 e^2/8), e = 1 - x y^2: error (5/16) e^3 ~ 2^-75 from v_rsq_f64's 2^-26; five instructions behind the
+    // seed where two Newton steps took eight
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y, fma(0.375, e, 0.5) * e, y);
 }
 
 // erfc(x) for 0 <= x <= 4 given ex = exp(-x*x), which the caller needs anyway (Fennell / Ewald force term):
-// erfc(x) = ex * p(t), t = 3u - 2, u = 1/(1 + x/2), p = our own degree-16 fit of erfcx (tools/fit_erfcx.py; max relative error
-// 8e-15 against scipy on [0, 4]).  24 instructions instead of ocml's 140-instruction erfc plus a second exp; the host selects
+// erfc(x) = ex * p(t), t = 3u - 2, u = 1/(1 + x/2), p = our own degree-15 fit of erfcx (tools/fit_erfcx.py; max relative error
+// 7e-14 against scipy on [0, 4]; degree 16 until round 4: 8.5e-15 for one more FMA per visit and two more scalar registers in a loop
+// that had run out of them).  23 instructions instead of ocml's 140-instruction erfc plus a second exp; the host selects
 // this kernel only when alpha * rc <= 4.  tests/test_gpu_parity.py checks the result against the oracle's libm erfc.
 // Coefficients live in constant memory so that they reach the polynomial chains through scalar registers: as 64-bit literals
 // every one of them costs a v_mov_b64 per use inside the pair loop (57 of the 199 VALU instructions of the Coulomb body).
 __constant__ double kCoulCoef[32] = {
-    // [0..16] erfcx fit, highest degree first
-    3.11400876136111478e-10, -6.43174152465694238e-10, -2.62442874509777347e-09, 1.54097035921259372e-08, -2.06548182619811564e-08,
-    -1.28511981631567555e-07, 7.28044471457273614e-07, -4.70993577663208179e-07, -9.92741548786899564e-06, 3.46017753152724625e-05,
-    1.00396629412378288e-04, -8.61280658253346654e-04, -1.60202363270953250e-03, 2.25095126335783415e-02, 1.42427001998883335e-01,
-    4.09818022175859609e-01, 4.27583576155806666e-01,
-    // [17..19] log2(e), ln2 high part (32 trailing zero bits), ln2 low part
+    // [0..15] erfcx fit, highest degree first
+    -6.42984581155711645e-10, -1.37711557461844240e-09, 1.54088012265774375e-08, -2.26846941341576436e-08, -1.28510332527685291e-07,
+    7.29764795089034142e-07, -4.70995058463941374e-07, -9.92822323014682285e-06, 3.46017759998636334e-05, 1.00396835324338853e-04,
+    -8.61280658405786780e-04, -1.60202365845927793e-03, 2.25095126335906476e-02, 1.42427002000104913e-01, 4.09818022175859442e-01,
+    4.27583576155797507e-01,
+    // [16..18] log2(e), ln2 high part (32 trailing zero bits), ln2 low part
     1.44269504088896338700e+00, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
-    // [20..30] 1/12! ... 1/2!  (exp Taylor series on |r| <= ln2/2: truncation 1.7e-16 relative)
-    2.08767569878680989792e-09, 2.50521083854417187751e-08, 2.75573192239858906526e-07, 2.75573192239858906526e-06,
-    2.48015873015873015873e-05, 1.98412698412698412698e-04, 1.38888888888888888889e-03, 8.33333333333333333333e-03,
-    4.16666666666666666667e-02, 1.66666666666666666667e-01, 5.00000000000000000000e-01,
-    0.0};
+    // [19..27] q(r) of exp(r) = 1 + r (1 + r q(r)) on |r| <= ln2/2, highest degree first (degree 8 fit of (e^r - 1 - r) / r^2: 1.2e-15 relative;
+    // the Taylor series to r^12 it replaced: 1.7e-16 for two more FMAs)
+    2.76223814036453055e-07, 2.76251616785559953e-06, 2.48015167924052650e-05, 1.98412086507197805e-04, 1.38888889198207112e-03,
+    8.33333335376915986e-03, 4.16666666666196950e-02, 1.66666666666482416e-01, 5.00000000000000222e-01,
+    0.0, 0.0, 0.0, 0.0};
 
-// exp(y) for -700 < y <= 0: n = rint(y log2 e), r = y - n ln2 (two-part), Taylor to r^12, scaled by 2^n.  ~21 instructions.
+// exp(y) for -700 < y <= 0: n = rint(y log2 e), r = y - n ln2 (two-part), 1 + r (1 + r q(r)), scaled by 2^n.  ~18 instructions.
+template <bool CLAMP = true>
 __device__ __forceinline__ double exp_nonpos(double y)
 {
-    y = fmax(y, -700.0);                           // masked-out pairs arrive with y = -1e299: keep the reduction finite (result ~1e-304)
-    const double n = rint(y * kCoulCoef[17]);
-    double r = fma(-n, kCoulCoef[18], y);
-    r = fma(-n, kCoulCoef[19], r);
-    double p = kCoulCoef[20];
+    if (CLAMP) y = fmax(y, -700.0);                // masked-out pairs arrive with y = -1e299: keep the reduction finite (result ~1e-304).  CLAMP = false: the
+                                                   // caller guarantees y > -700 (the list kernel's Coulomb bodies: pairs outside the cut-off never get here and
+                                                   // alpha r <= 4)
+    const double n = rint(y * kCoulCoef[16]);
+    double r = fma(-n, kCoulCoef[17], y);
+    r = fma(-n, kCoulCoef[18], r);
+    double p = kCoulCoef[19];
 #pragma unroll
-    for (int k = 21; k <= 30; k++) p = fma(p, r, kCoulCoef[k]);
+    for (int k = 20; k <= 27; k++) p = fma(p, r, kCoulCoef[k]);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return ldexp(p, (int)n);
@@ -175,10 +180,14 @@ __device__ __forceinline__ double exp_nonpos(double y)
 
 __device__ __forceinline__ double erfc_given_exp(double x, double ex)
 {
-    const double t = fma(3.0, fast_rcp(fma(0.5, x, 1.0)), -2.0);
+    // (1 / (1 + x/2) by ONE Newton step behind v_rcp_f64: 2^-52 relative - t feeds a polynomial whose value moves by about as much -, one FMA less than fast_rcp)
+    const double a = fma(0.5, x, 1.0);
+    double u = __builtin_amdgcn_rcp(a);
+    u = fma(u, fma(-a, u, 1.0), u);
+    const double t = fma(3.0, u, -2.0);
     double p = kCoulCoef[0];
 #pragma unroll
-    for (int k = 1; k <= 16; k++) p = fma(p, t, kCoulCoef[k]);
+    for (int k = 1; k <= 15; k++) p = fma(p, t, kCoulCoef[k]);
     return ex * p;
 }
 

@@ -223,7 +223,8 @@ __global__ __launch_bounds__(MULTI ? kWave * kListMaxWaves : kWave) void k_pair_
         // ---- every lane walks its list
         PairAcc acc = {0, 0, 0, 0, 0, 0};
         int nDropHalf = 0;
-        const double ljDropR2 = P.ljDropR2;
+        double ljDropR2 = P.ljDropR2;
+        if (kTab) asm volatile("" : "+v"(ljDropR2));                   // (table-driven modes: a vector register, like the uniforms of PairHot - see there)
         const PairHot hot = kTab ? pair_hot_in_vgprs(P, lj) : (MODE == 1 ? pair_hot_lj_in_vgprs(P, lj) : pair_hot(P, lj));
         const int nChunks = (nIter + 7) >> 3;
         // software-pipelined: the candidate of iteration t + 1 is read from LDS before the potential of iteration t is evaluated (entries behind a lane's

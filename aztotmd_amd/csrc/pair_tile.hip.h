@@ -85,17 +85,19 @@ constexpr int kLjSpecMax = 4;      // MODE 2 keeps the per-species-pair Lennard-
 // s_waitcnt lgkmcnt(0) that follows also waits for the LDS reads of the next candidate issued just before - the software pipelining was gone.
 // ljA2 (one-species Lennard-Jones body): 48 eps sigma^12, the coefficient of the force polynomial's FMA - a vector register in the list kernel, because an FMA
 // takes ONE scalar operand and the other constant (-24 eps sigma^6) already is one: left to itself the compiler copied a constant into vector registers on every visit
-struct PairHot { double r2Max, alpha, ljA2; };
-__device__ __forceinline__ PairHot pair_hot(const StepParams& P, const DevPot& lj) { return PairHot{P.r2Max, P.alpha, lj.p4}; }
+// elScale2, daipi2 (Fennell / Ewald bodies): round 4 found the list kernel's Fennell loop re-loading both from the kernel arguments on EVERY visit (and reading two
+// spilled polynomial coefficients back with v_readlane): the loop had run out of scalar registers again.
+struct PairHot { double r2Max, alpha, ljA2, elScale2, daipi2; };
+__device__ __forceinline__ PairHot pair_hot(const StepParams& P, const DevPot& lj) { return PairHot{P.r2Max, P.alpha, lj.p4, P.el_scale2, P.daipi2}; }
 __device__ __forceinline__ PairHot pair_hot_in_vgprs(const StepParams& P, const DevPot& lj)
 {
-    PairHot h{P.r2Max, P.alpha, lj.p4};
-    asm volatile("" : "+v"(h.r2Max), "+v"(h.alpha));
+    PairHot h{P.r2Max, P.alpha, lj.p4, P.el_scale2, P.daipi2};
+    asm volatile("" : "+v"(h.r2Max), "+v"(h.alpha), "+v"(h.elScale2), "+v"(h.daipi2));
     return h;
 }
 __device__ __forceinline__ PairHot pair_hot_lj_in_vgprs(const StepParams& P, const DevPot& lj)
 {
-    PairHot h{P.r2Max, P.alpha, lj.p4};
+    PairHot h{P.r2Max, P.alpha, lj.p4, P.el_scale2, P.daipi2};
     asm volatile("" : "+v"(h.ljA2));
     return h;
 }
@@ -163,8 +165,10 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
         // MODE 5 = MODE 2 with the electrostatics known when the kernel is compiled (Fennell/DSF): no wave-uniform branches inside the pair loop, which cost
         // MODE 2 its instruction scheduling (every table read waited for on the spot) and, with three variants of the body alive, its scalar registers
         const double* pp = pairTab + (ti * P.nSpec + tj) * kPairTabStride;
-        const double tabP1 = pp[1], tabP2 = pp[2], tabCut = pp[5], tabKqq = pp[6];      // read whatever the pair turns out to be: the reads travel together
-        const bool pairOk = live & (r2 > 0.0) & (r2 <= H.r2Max);
+        // (Lennard-Jones family: slots 3 and 4 hold the force polynomial's constants 24 eps sigma^6 and 48 eps sigma^12, Engine::allocate - see MODE 1)
+        const double tabP1 = (VDW == 1) ? pp[3] : pp[1], tabP2 = (VDW == 1) ? pp[4] : pp[2], tabCut = pp[5], tabKqq = pp[6];      // read whatever the pair turns out to be: the reads travel together
+        // (MASKED = the list kernel: an atom is never on its own list and idle lanes never meet the dummy candidate at r = 0, so r^2 > 0 needs no test)
+        const bool pairOk = live & (MASKED || r2 > 0.0) & (r2 <= H.r2Max);
         if (MASKED && !pairOk) return;
         const double r2s = (MASKED || pairOk) ? r2 : 1e300;
         const bool coul = (MODE == 3) || (MODE == 5) || (P.elec_type != 0);               // wave-uniform
@@ -175,11 +179,15 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
         const bool vdwOk = r2s <= tabCut;
         double f;
         if (VDW == 1)
-        {   // fer_lj vdw.cpp:16-26: p0 = 4 eps, p1 = sigma^2, p2 = 24 eps
-            const double sr2 = vdwOk ? tabP1 * r2i : 0.0;
-            const double sr6 = sr2 * sr2 * sr2;
-            ra.eV = fma(0.5 * pp[0], sr6 * (sr6 - 1.0), ra.eV);
-            f = tabP2 * r2i * sr6 * (2.0 * sr6 - 1.0);
+        {   // fer_lj vdw.cpp:16-26 (p0 = 4 eps, p1 = sigma^2, p2 = 24 eps) as the polynomial f = u^4 (A2 u^3 - A1) in u = 1 / r^2, as in MODE 1
+            const double u2 = r2i * r2i, u3 = u2 * r2i;
+            const double fl = (u2 * u2) * fma(tabP2, u3, -tabP1);
+            f = vdwOk ? fl : 0.0;
+            {   // energy (launches that book energies only)
+                const double s2 = pp[1];
+                const double sr6 = vdwOk ? (s2 * s2 * s2) * u3 : 0.0;
+                ra.eV = fma(0.5 * pp[0], sr6 * (sr6 - 1.0), ra.eV);
+            }
         }
         else
         {
@@ -218,19 +226,19 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
         {
             const double kqq = (MASKED || pairOk) ? tabKqq : 0.0;
             const double ar = H.alpha * r;
-            const double ex = exp_nonpos(-ar * ar);
+            const double ex = exp_nonpos<!MASKED>(-ar * ar);
             const double erfcar = erfc_given_exp(ar, ex);
-            ra.eC = fma(0.5 * kqq, erfcar * ir - P.el_scale + P.el_scale2 * (r - P.rReal), ra.eC);
-            f = fma(kqq * ir, (erfcar * r2i + P.daipi2 * ex * ir) - P.el_scale2, f);
+            ra.eC = fma(0.5 * kqq, erfcar * ir - P.el_scale + H.elScale2 * (r - P.rReal), ra.eC);
+            f = fma(kqq * ir, (erfcar * r2i + H.daipi2 * ex * ir) - H.elScale2, f);
         }
         else if (MODE == 3)
         {   // real-space term of the Ewald sum: coul_iter elec.cpp:344-369 (real_ewald cuElec.cu:94-113)
             const double kqq = (MASKED || pairOk) ? tabKqq : 0.0;
             const double ar = H.alpha * r;
-            const double ex = exp_nonpos(-ar * ar);
+            const double ex = exp_nonpos<!MASKED>(-ar * ar);
             const double erfcar = erfc_given_exp(ar, ex);
             ra.eC = fma(0.5 * kqq, erfcar * ir, ra.eC);
-            f = fma(kqq * ir * r2i, fma(P.daipi2 * r, ex, erfcar), f);
+            f = fma(kqq * ir * r2i, fma(H.daipi2 * r, ex, erfcar), f);
         }
         else if (MODE == 2 && P.elec_type == 1)
         {   // direct_coul elec.cpp:415-428
