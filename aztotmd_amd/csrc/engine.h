@@ -212,6 +212,7 @@ private:
     double lazyMargin_ = 1.15;         // one GPU: K steps of the longest step seen may use slack / lazyMargin_ (1.3 until round 4: 20 000 steps of C4T and 10 000 of C3T run
                                        // without a violation at 1.05 too); widened by every violation (a system that heats up)
     bool lazyMeasured_ = false;     // the interval has been sized from a measurement at least once
+    double lastLookLen_ = 0.0;      // the longest step of the window before the last look (0: none to compare with): growing speeds widen the margin
     int sinceSort_ = 1 << 30;       // plain steps since the last sort
     long long rebuilds_ = 0;        // steps that rebuilt the cell list so far
     double lazySlack_ = 0.0;

@@ -1803,7 +1803,13 @@ bool Engine::adapt_sort_interval()
             const double len = std::sqrt(ms2);
             // (slab ranks repair a violation by running up to a window of steps again with the cells rebuilt every step - dearer than the wider stencil one GPU
             //  falls back on - so they keep a factor 2 in hand at least; round 2 kept 4 and could only report the violation)
-            const double raw = len > 0 ? lazySlack_ / ((nranks_ > 1 ? std::max(2.0, lazyMargin_) : lazyMargin_) * len) : 1e9;
+            // ... and where the speeds are still growing (a lattice released from rest, a melt heating up: the longest step of this window against the last
+            // one's) the margin grows by the same factor, at most 2: the steps ahead will be longer than the ones just seen.  (With the plain margin of 1.15
+            // C3 - charges on a lattice at rest - ran into a violation in its first hundred steps; a first look has nothing to compare with and takes 1.3.)
+            // (a ratio below 1.1 is the noise of a maximum over a few thousand atom-steps, not a trend)
+            const double growth = lastLookLen_ > 0.0 ? (len > 1.1 * lastLookLen_ ? std::min(2.0, len / lastLookLen_) : 1.0) : 1.3 / 1.15;
+            lastLookLen_ = len;
+            const double raw = len > 0 ? lazySlack_ / ((nranks_ > 1 ? std::max(2.0, lazyMargin_) : lazyMargin_) * growth * len) : 1e9;
             if (std::getenv("AZTOT_VERBOSE"))
                 std::fprintf(stderr, "aztot: longest step %.3e A, slack %.3e A, margin %.2f%s: interval up to %.1f steps\n", len, lazySlack_, lazyMargin_, violated ? ", violated" : "", raw);
             static const int allowed[] = {128, 112, 96, 80, 64, 56, 48, 40, 36, 32, 28, 24, 20, 16, 14, 12, 10, 8, 6, 5, 4, 3, 2, 1};
@@ -2005,7 +2011,7 @@ void Engine::set_state(const aztot_state& in)
     if (in.vx || in.vy || in.vz || in.fx || in.fy || in.fz)
     {   // new velocities / forces: the interval measured on the old ones says nothing about them - every step rebuilds until the first look
         if (lazyK_ != 1 && !(debug_ & 8192)) { lazyK_ = 1; destroy_graphs(); graphCycle_ = 0; }
-        lazyMeasured_ = false; lazyWindow_ = 8; sinceLook_ = 0;
+        lazyMeasured_ = false; lazyWindow_ = 8; sinceLook_ = 0; lastLookLen_ = 0.0;
     }
     Counts c;
     HIP_CHECK(hipMemcpy(&c, dCounts_, sizeof(Counts), hipMemcpyDeviceToHost));
