@@ -75,6 +75,33 @@ __device__ __forceinline__ void add_partial(double* partials, int maxBlocks, int
 {
     partials[(size_t)slot * maxBlocks + blockIdx.x] += v;
 }
+
+// Wall momenta and crossing counts of a workgroup into its partial-sum slots (put_periodic's counters, box.cpp:230-295 / cuMDfunc.cu:72-106).  A handful of
+// atoms per step cross a wall in a box of a million, but the workgroup that holds one used to run twelve block reductions (24 barriers) for it - every wave of
+// it -, and an integrate kernel is as slow as its slowest workgroup: k_integrate_plain2 took 31.7 us on the thermalised 1 M-atom box against 27.1 on the
+// lattice at rest.  Now: one barrier for everybody, twelve wave reductions in the waves that have a crossing, one more barrier and twelve short sums in the
+// workgroups that have one.  Same order of summation as block_sum (inside a wave, then the waves in order): the sums are bit-identical.
+__device__ __forceinline__ void book_wall_crossings(const double (&mom)[6], const double (&cross)[6], int anyCross, double* __restrict__ partials, int maxBlocks)
+{
+    __shared__ double wall[kBlock / kWave][12];
+    if (!__syncthreads_or(anyCross)) return;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const bool mine = __any(anyCross) != 0;                            // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+    {
+        const double a = mine ? wave_sum(mom[k]) : 0.0, b = mine ? wave_sum(cross[k]) : 0.0;
+        if (lane == 0) { wall[w][k] = a; wall[w][6 + k] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6)
+    {
+        const int k = threadIdx.x;
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < (int)(blockDim.x >> 6); q++) { a += wall[q][k]; b += wall[q][6 + k]; }
+        if (b != 0.0) { add_partial(partials, maxBlocks, PS_MOM_XN + k, a); add_partial(partials, maxBlocks, PS_CNT_XN + k, b); }
+    }
+}
 __device__ __forceinline__ bool slot_accumulates(int slot) { return (slot >= PS_MOM_XN && slot <= PS_CNT_ZP) || slot == PS_DROPPED; }
 
 // ------------------------------------------------------------------------------------------------
@@ -513,12 +540,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate1_bin(StepParams P, SpecTab
         double s = 0.0;
         if (P.E[0] != 0.0 || P.E[1] != 0.0 || P.E[2] != 0.0) s = block_sum(eField, scratch);
         if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EFIELD, s);
-        if (__syncthreads_or(anyCross))                         // wall crossings are rare: skip 12 reductions otherwise
-            for (int k = 0; k < 6; k++)
-            {
-                const double a = block_sum(mom[k], scratch), b = block_sum(cross[k], scratch);
-                if (threadIdx.x == 0 && b != 0.0) { add_partial(partials, maxBlocks, PS_MOM_XN + k, a); add_partial(partials, maxBlocks, PS_CNT_XN + k, b); }
-            }
+        book_wall_crossings(mom, cross, anyCross, partials, maxBlocks);
     }
 }
 
@@ -601,13 +623,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate_plain2(StepParams P, SpecT
         }
     }
     if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EFIELD, 0.0);
-    if (__syncthreads_or(anyCross))
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-        {
-            const double a = block_sum(mom[k], scratch), b = block_sum(cross[k], scratch);
-            if (threadIdx.x == 0 && b != 0.0) { add_partial(partials, maxBlocks, PS_MOM_XN + k, a); add_partial(partials, maxBlocks, PS_CNT_XN + k, b); }
-        }
+    book_wall_crossings(mom, cross, anyCross, partials, maxBlocks);
 }
 
 // The dynamic state in one launch (Engine::take_snapshot / replay_from_snapshot: sixteen separate copies cost a short aztot_step call more host time than its
@@ -1190,13 +1206,7 @@ __global__ __launch_bounds__(kBlock) void k_boundary_radi(StepParams P, SpecTabl
         }
     }
     if (threadIdx.x == 0) put_partial(partials, maxBlocks, PS_EFIELD, 0.0);
-    if (__syncthreads_or(anyCross))
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-        {
-            const double a = block_sum(mom[k], scratch), b = block_sum(cross[k], scratch);
-            if (threadIdx.x == 0 && b != 0.0) { add_partial(partials, maxBlocks, PS_MOM_XN + k, a); add_partial(partials, maxBlocks, PS_CNT_XN + k, b); }
-        }
+    book_wall_crossings(mom, cross, anyCross, partials, maxBlocks);
 }
 
 // ------------------------------------------------------------------------------------------------
