@@ -40,6 +40,7 @@ enum DebugBit : unsigned
     DBG_KICK_EVERY_STEP = 128,           // k_integrate2 launched every step
     DBG_LARGE_KICK_PATH = 256,           // the deferred half-kick of large systems whatever the size
     DBG_GENERIC_PAIR = 512,              // the generic (switch-based) pair body instead of a specialised mode
+    DBG_KEEP_VDW_CUT_TEST = 1024,        // Lennard-Jones family: keep the per-pair cut-off test although it always passes (family 6, Engine::construct)
     DBG_STAGE_ONLY = 2048,               // NOT result-preserving: the staging pair kernel stages its tile and stops (phase timing)
     DBG_SLAB_GRAPH = 4096,               // hipGraph replay of a loopback slab rank
     DBG_FIXED_INTERVAL = 8192,           // lazy re-sort at the fixed interval options.sort_every whatever the atoms' speed (exercises the wider-stencil fallback)

@@ -234,6 +234,13 @@ void Engine::construct()
         P_.pad1 = uniform ? 2 : 0;
         P_.vdwFamily = uniform ? family : 0;
         if (uniform && family == AZTOT_VDW_LJ)
+        {   // family 6 = Lennard-Jones where EVERY species pair has a potential and none of their cut-offs lies inside the pair test's r2Max (the usual input:
+            // one cut-off for everything, C3): the per-pair cut-off test - a table read, a compare and two selects per visit - always passes and is compiled out
+            bool always = true;
+            for (const auto& p : m.pairpots) if (p.type != AZTOT_VDW_LJ || p.r2cut < m.r2Max) always = false;
+            if (always && !(debug_ & 1024)) P_.vdwFamily = 6;          // (debug bit 1024: keep the test)
+        }
+        if (uniform && family == AZTOT_VDW_LJ)
         {   // the same shortcut for the Lennard-Jones family with charges: |f| <= |f_LJ| + |f_Coulomb|, each held below 0.5e5 beyond its radius.  LJ part
             // as above per species pair; Coulomb part (direct, Fennell, real-space Ewald alike): |f| <= |kqq| (1/r^3 + (2 alpha/sqrt pi)/r^2 + S2/r)
             double r2 = 0.0;

@@ -166,19 +166,20 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
         // MODE 2 its instruction scheduling (every table read waited for on the spot) and, with three variants of the body alive, its scalar registers
         const double* pp = pairTab + (ti * P.nSpec + tj) * kPairTabStride;
         // (Lennard-Jones family: slots 3 and 4 hold the force polynomial's constants 24 eps sigma^6 and 48 eps sigma^12, Engine::allocate - see MODE 1)
-        const double tabP1 = (VDW == 1) ? pp[3] : pp[1], tabP2 = (VDW == 1) ? pp[4] : pp[2], tabCut = pp[5], tabKqq = pp[6];      // read whatever the pair turns out to be: the reads travel together
+        constexpr bool kLJ = (VDW == 1 || VDW == 6);                  // VDW 6: Lennard-Jones whose per-pair cut-off test always passes (Engine::construct)
+        const double tabP1 = kLJ ? pp[3] : pp[1], tabP2 = kLJ ? pp[4] : pp[2], tabCut = (VDW == 6) ? 0.0 : pp[5], tabKqq = pp[6];      // read whatever the pair turns out to be: the reads travel together
         // (MASKED = the list kernel: an atom is never on its own list and idle lanes never meet the dummy candidate at r = 0, so r^2 > 0 needs no test)
         const bool pairOk = live & (MASKED || r2 > 0.0) & (r2 <= H.r2Max);
         if (MASKED && !pairOk) return;
         const double r2s = (MASKED || pairOk) ? r2 : 1e300;
         const bool coul = (MODE == 3) || (MODE == 5) || (P.elec_type != 0);               // wave-uniform
-        const bool needR = coul || VDW != 1;
+        const bool needR = coul || !kLJ;
         const double ir = needR ? fast_rsqrt(r2s) : 0.0;
         const double r2i = needR ? ir * ir : fast_rcp(r2s);
         const double r = r2s * ir;
-        const bool vdwOk = r2s <= tabCut;
+        const bool vdwOk = (VDW == 6) || r2s <= tabCut;
         double f;
-        if (VDW == 1)
+        if (kLJ)
         {   // fer_lj vdw.cpp:16-26 (p0 = 4 eps, p1 = sigma^2, p2 = 24 eps) as the polynomial f = u^4 (A2 u^3 - A1) in u = 1 / r^2, as in MODE 1
             const double u2 = r2i * r2i, u3 = u2 * r2i;
             const double fl = (u2 * u2) * fma(tabP2, u3, -tabP1);
@@ -249,7 +250,7 @@ __device__ __forceinline__ void pair_body(const StepParams& P, const SpecTable& 
         // integrators.cpp:170-174: a pair with f^2 > 1e10 is dropped.  Lennard-Jones family: beyond ljDropR2 neither part of the force can get there
         // (Engine::construct), so the exact test is a wave-uniform branch a liquid never takes; the other families test every pair
         double fm = f;
-        if (VDW != 1 || __builtin_expect(__any(r2s < ljDropR2), 0))
+        if (!kLJ || __builtin_expect(__any(r2s < ljDropR2), 0))
         {
             const bool tooBig = f * f > 1e10;
             nDropHalf += tooBig ? 1 : 0;
@@ -952,6 +953,7 @@ inline void launch_pair_tile_as(const StepParams& P, const SpecTable& S, const D
             case 3: if (ew) LAUNCH<3, 3>(__VA_ARGS__); else if (P.elec_type == 3) LAUNCH<5, 3>(__VA_ARGS__); else LAUNCH<2, 3>(__VA_ARGS__); return; \
             case 4: if (ew) LAUNCH<3, 4>(__VA_ARGS__); else if (P.elec_type == 3) LAUNCH<5, 4>(__VA_ARGS__); else LAUNCH<2, 4>(__VA_ARGS__); return; \
             case 5: if (ew) LAUNCH<3, 5>(__VA_ARGS__); else if (P.elec_type == 3) LAUNCH<5, 5>(__VA_ARGS__); else LAUNCH<2, 5>(__VA_ARGS__); return; \
+            case 6: if (ew) LAUNCH<3, 6>(__VA_ARGS__); else if (P.elec_type == 3) LAUNCH<5, 6>(__VA_ARGS__); else LAUNCH<2, 6>(__VA_ARGS__); return; \
             }                                                                                              \
         }                                                                                                  \
         LAUNCH<0, 0>(__VA_ARGS__);                                                                         \
