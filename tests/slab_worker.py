@@ -95,9 +95,20 @@ def main():
             eng.step(nsteps - first)
         except api.AztotError as ex:
             code, msg = ex.code, str(ex)
+        # ... and the handle is dead for stepping from then on (the first error is repeated), alive for a post-mortem read of the clock
+        again, again_msg, clock_ok = 0, "", False
+        try:
+            eng.step(1)
+        except api.AztotError as ex:
+            again, again_msg = ex.code, str(ex)
+        try:
+            clock_ok = eng.clock()["step"] >= 0
+        except api.AztotError:
+            clock_ok = False
         codes = cp.all_gather(code)
+        agains = cp.all_gather([again, "earlier call" in again_msg, bool(clock_ok)])
         if rank == 0:
-            print("SLAB_RESULT " + json.dumps({"world": world, "transport": transport, "codes": codes, "message": msg}))
+            print("SLAB_RESULT " + json.dumps({"world": world, "transport": transport, "codes": codes, "message": msg, "after_failure": agains}))
         cp.barrier()
         cp.close()
         return

@@ -148,6 +148,9 @@ def test_neighbours_that_disagree_about_their_boundary_atoms_fail_before_any_pla
     out = run_ranks(2, "lj", 40, port=29690, transport="callback_corrupt")
     assert out["codes"] == [-5, -5], out
     assert "disagree about their boundary atoms" in out["message"], out
+    # a failed handle refuses to step on (first error repeated) and still answers a post-mortem read
+    for code, repeated, clock_ok in out["after_failure"]:
+        assert code < 0 and repeated and clock_ok, out
 
 
 def test_rccl_library_selftest():
