@@ -109,8 +109,27 @@ def launch_ranks(n, argv):
         t.start()
     worst, first_failure = 0, None
     live = set(range(n))
+    # a rank that hangs (a collective its neighbour never joins) must not hold the node for ever: after AZTOT_BENCH_TIMEOUT seconds (default 900) the launcher ends
+    # exactly the process groups it started and reports 124, like timeout(1)
+    deadline = time.time() + float(os.environ.get("AZTOT_BENCH_TIMEOUT", "900"))
     try:
         while live:
+            if time.time() > deadline:
+                sys.stderr.write("bench.py launcher: ranks %s still running after the time limit - ending them\n" % sorted(live))
+                for r in sorted(live):
+                    try:
+                        os.killpg(procs[r].pid, signal.SIGTERM)
+                    except OSError:
+                        pass
+                time.sleep(5.0)
+                for r in sorted(live):
+                    if procs[r].poll() is None:
+                        try:
+                            os.killpg(procs[r].pid, signal.SIGKILL)
+                        except OSError:
+                            pass
+                worst = max(worst, 124)
+                break
             for r in sorted(live):
                 rc = procs[r].poll()
                 if rc is None:
@@ -234,6 +253,8 @@ def main():
         mine = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid(), "ppid": os.getppid(), "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
                 "token_set": bool(os.environ.get("AZTOT_CTL_TOKEN")), "gpu_libraries": mapped_gpu_libraries()}
         ranks = cp.all_gather(mine)
+        if os.environ.get("AZTOT_DRY_RUN_HANG") and rank == 1:
+            time.sleep(3600)            # (test of the launcher's time limit: a rank that never joins the next collective)
         if rank == 0:
             os.dup2(real_stdout, 1)
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": ranks, "launcher_pid": int(lp) if lp else None,

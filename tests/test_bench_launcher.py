@@ -82,3 +82,12 @@ def test_one_gpu_line_is_what_it_was():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["metric"] == "ns_per_day" and out["n_gpus"] == 1 and out["steps"] == 20 and out["value"] > 0
     assert out["roofline"]["frac"] > 0 and out["config"]["transport"] == "single GPU"
+
+
+def test_the_launcher_ends_ranks_that_hang():
+    """a rank stuck in a collective must not hold the node: the launcher's time limit ends the process groups it started and reports 124"""
+    env = clean_env()
+    env.update(AZTOT_BENCH_TIMEOUT="3", AZTOT_DRY_RUN_HANG="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
+    assert "time limit" in r.stderr
