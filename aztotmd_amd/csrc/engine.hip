@@ -289,7 +289,11 @@ void Engine::construct()
         // On 1 M atoms that 13-lane read-modify-write of the velocities makes L2 write lines back several times (rocprofv3: 221 MB
         // instead of 63 + 76 MB per step) for no gain, so large systems fold it into the next step's streaming k_integrate1_bin.
         fuseEpilogue_ = plainNve && variant >= 2 && capacity_ <= kFuseKickMaxAtoms && !(debug_ & 256);   // debug bit 256: large-system path
-        lazyKick_ = plainNve && !fuseEpilogue_;
+        // (bonded and reciprocal-space forces are added behind the pair kernel and are complete before the next step's integrate kernel just the same: runs with
+        //  bonds / angles / the Ewald sum defer the kick too - they cannot take the pair kernel's epilogue, which would kick with the pair forces alone.
+        //  M4: one 17 us launch per step less)
+        const bool kickCanWait = !(P_.nEq > 0) && P_.tstat == AZTOT_TSTAT_NONE && !(debug_ & 128);
+        lazyKick_ = kickCanWait && !fuseEpilogue_;
         P_.pad2 = 0;
         // next-step fusion (NextStep, pair_tile.hip.h): plain NVE (nothing happens between the forces and the next half-kick; on slab ranks the coordinate
         // exchange of the next step simply follows the pair kernel that produced the coordinates), a lazy run that walks
