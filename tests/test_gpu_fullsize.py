@@ -297,3 +297,49 @@ def test_thermalised_liquid_at_full_size(name):
         f.step(n)
     stf = f.stats()
     assert stf["sort_interval"] >= 10 and stf["sort_violations"] == 0 and stf["pair_lists"] == 1 and stf["cells_without_list"] == 0, stf
+
+
+def test_random_call_pattern_at_full_size():
+    """the call-pattern fuzz (tests/test_gpu_call_patterns.py) at the size the bench runs: C4T, 1 000 188 atoms - the default engine (adaptive interval, pair lists,
+    no clean-up launch with 100 MB snapshots, call ends deferred to the next look or read) against the every-step schedule under random aztot_step sizes,
+    single-step loops, statistics reads, aztot_forces, a heating kick and an in-place restart"""
+    rng = np.random.default_rng(7)
+    case = inputs.config("C4T")
+    a = api.Engine(api.Model.from_case(case))
+    b = api.Engine(api.Model.from_case(case), sort_every=1)
+    total = 0
+    while total < 260:
+        op = rng.choice(["step", "step", "step1", "stats", "forces", "heat", "restart"])
+        if op == "step":
+            n = int(rng.choice([2, 5, 13, 34, 89]))
+            a.step(n); b.step(n); total += n
+        elif op == "step1":
+            n = int(rng.integers(1, 12))
+            for _ in range(n):
+                a.step(1); b.step(1)
+            total += n
+        elif op == "stats":
+            sa, sb = a.stats(), b.stats()
+            for k in ("engTot", "engKin", "engVdW"):
+                assert abs(sa[k] - sb[k]) <= 1e-10 * abs(sb[k]), (total, k, sa[k], sb[k])
+        elif op == "forces":
+            a.forces(); b.forces()
+        elif op == "heat":
+            f = float(rng.uniform(0.95, 1.15))
+            for e in (a, b):
+                s = e.state(("vx", "vy", "vz"))
+                e.set_state(**{k: s[k] * f for k in ("vx", "vy", "vz")})
+        else:
+            for e in (a, b):
+                s = e.state(XVF)
+                c = e.clock()
+                e.set_state(**{k: s[k] for k in XVF})
+                e.set_clock(**c)
+    sa, sb, xa, xb = a.stats(), b.stats(), a.state(XVF), b.state(XVF)
+    assert sa["step"] == sb["step"] == total and sa["sort_interval"] > 1 and sb["sort_interval"] == 1
+    for k in XVF:
+        assert rel_err(xa[k], xb[k]) < 1e-9, (k, rel_err(xa[k], xb[k]))
+    assert per_atom_err(xa, xb, FRC) < 1e-8
+    for k in ("engTot", "engKin", "engVdW"):
+        assert abs(sa[k] - sb[k]) <= 1e-10 * abs(sb[k]), (k, sa[k], sb[k])
+    assert sa["posCross"] == sb["posCross"] and sa["negCross"] == sb["negCross"]
