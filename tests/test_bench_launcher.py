@@ -82,6 +82,33 @@ def test_one_gpu_line_is_what_it_was():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["metric"] == "ns_per_day" and out["n_gpus"] == 1 and out["steps"] == 20 and out["value"] > 0
     assert out["roofline"]["frac"] > 0 and out["config"]["transport"] == "single GPU"
+    # the driver's contract, field by field
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "library"):
+        assert k in out, k
+    assert out["unit"] == "ns/day" and out["higher_is_better"] is True and out["dtype"] == "f64" and out["data"] == "synthetic" and out["vs_baseline"] is None
+    assert "workload" in out["config"] and "model" not in out["config"]
+    r = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # PMC-derived numbers are either those of THIS build or null with the reason
+    assert (r["traffic"] is None) == (r.get("counters_from") is None)
+    assert out["steady_state"]["ms_per_step"] > 0 and out["call_overhead"]["step1_ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_cpu_baseline_leg_and_same_run_parity():
+    """the serial CPU path timed beside the GPU in the same run (the reference's own code when its binary travelled, else our port), with the energies of both"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--workload", "C2", "--steps", "20", "--warmup", "5", "--no-steady", "--cpu-steps", "3"], capture_output=True, text=True,
+                       timeout=600, env=clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    c = out["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 0
+    if c["kind"] == "reference":
+        assert c["same_run_parity"]["engTot_rel_diff"] < 1e-11, c["same_run_parity"]
 
 
 def test_the_launcher_ends_ranks_that_hang():
