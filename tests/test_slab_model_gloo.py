@@ -1,4 +1,4 @@
-"""CPU test (gloo, world_size 2 and 3): the slab-decomposition protocol (ownership by cell layer, emigrants kept as
+"""CPU test (gloo, world_size 2, 3 and 4): the slab-decomposition protocol (ownership by cell layer, emigrants kept as
 ghosts, one message per neighbour and step) reproduces the single-domain oracle.  The device implementation
 (aztotmd_amd/csrc/slab.hip.h) follows the same rules and is tested against the single-rank engine with -m gpu."""
 import json
@@ -11,7 +11,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world,port", [(2, 29631), (3, 29632)])
+@pytest.mark.parametrize("world,port", [(2, 29631), (3, 29632), (4, 29635)])
 def test_slab_protocol_model_matches_single_domain(world, port):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "slab_model.py"), "12"]
@@ -23,7 +23,7 @@ def test_slab_protocol_model_matches_single_domain(world, port):
     assert out["err"][""] < 1e-11 and out["err"]["v"] < 1e-10 and out["err"]["f"] < 1e-11 * max(out["fmax"], 1.0), out
 
 
-@pytest.mark.parametrize("world,K,port", [(2, 12, 29633), (3, 6, 29634)])
+@pytest.mark.parametrize("world,K,port", [(2, 12, 29633), (3, 6, 29634), (4, 12, 29636)])
 def test_slab_ranks_repair_a_skin_violation_together(world, K, port):
     """The lazy re-sort on slab ranks (cells rebuilt every K-th step, coordinates only in between) with looks every 8 steps: K = 12 lets the fastest atoms of
     this 3 000 K gas leave the slack (0.35 A) before the scheduled rebuild - the look that finds it takes every rank back to its snapshot and runs the window
